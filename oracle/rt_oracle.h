@@ -1,0 +1,181 @@
+/*
+ * rt_oracle.h -- CPU restatement of the philae-ael/Raytracing render path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is the checker the HIP path is
+ * compared against; nothing in the product (raytracing_amd/) may link, load or
+ * call it.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it.
+ *
+ * What it restates (paths relative to the reference checkout):
+ *   scene build      crates/rt/src/aggregate/embree.rs:19-79,164-266
+ *   closest hit      crates/rt/src/aggregate/embree.rs:100-140
+ *   path tracer      crates/rt/src/integrators/pathtracing.rs:21-79
+ *   random walk      crates/rt/src/integrators/randomwalk.rs:24-68
+ *   sky              crates/rt/src/integrators/mod.rs:8-23
+ *   materials        crates/rt/src/material/mod.rs:56-394
+ *   distributions    crates/rt/src/math/distributions.rs:86-95,120-130,176-265
+ *   frame            crates/rt/src/math/transform.rs:63-94
+ *   vector helpers   crates/rt/src/math/vec.rs:14-52
+ *   camera           crates/rt/src/camera.rs:35-107
+ *   sampler, filter  crates/rt/src/sampler.rs:91-112, crates/rt/src/filter.rs:20-33
+ *   pixel driver     crates/rt-cli/src/executor.rs:207-270
+ *   accumulate       crates/rt/src/renderer.rs:36-96, crates/rt/src/math/stat.rs:10-52,147-183
+ *   sRGB             crates/rt/src/color/colorspace.rs:71-80
+ *   tiles            crates/rt-cli/src/tile.rs:56-97
+ *
+ * PARITY STATUS: the ray/primitive arithmetic of the reference lives in Intel
+ * Embree 4 (embree4-rs 0.0.7 / embree4-sys 0.0.10, un-vendored path
+ * dependencies), which is absent, and none of the reference's own tests pins
+ * an intersection or radiance value.  The closest-hit contract is therefore
+ * restated from Embree's published semantics (closest hit in (tnear, tfar],
+ * triangle Ng = (v1-v0)x(v2-v0), sphere Ng = hit - centre, no culling) using
+ * Moeller-Trumbore for triangles and Embree's sphere-point formulation.  The
+ * restatement is pinned at image level against the reference's committed
+ * 1920x1080 Cornell-box renders (tests/golden/cornell100), which fix camera,
+ * geometry, material assignment and converged radiance to 8-bit precision.
+ * Per-ray hit distances are "parity unpinned" beyond that.
+ *
+ * Two deliberate departures, shared with the HIP path so both can be compared
+ * bit for bit:
+ *   - random numbers come from Philox4x32-10 keyed by (seed, x, y, sample,
+ *     stream) instead of SipHash-seeded Xoshiro256** (crates/rt/src/lib.rs:41-47,
+ *     crates/rt/src/sampler.rs:27-31); the property "a sample depends only on
+ *     x, y, sample index and seed" (crates/rt-cli/src/main.rs:65-68) is kept;
+ *   - sin/cos of 2*pi*u are evaluated by a fixed polynomial in IEEE
+ *     add/multiply only, so that CPU and GPU agree to the last bit.
+ * Everything is f32 arithmetic in the written order; build with
+ * -ffp-contract=off.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_MAT_DIFFUSE = 0, ORC_MAT_DIELECTRIC = 1, ORC_MAT_THIN_DIELECTRIC = 2, ORC_MAT_EMIT = 3 };
+enum { ORC_INTEGRATOR_PATH_TRACER = 0, ORC_INTEGRATOR_RANDOM_WALK = 1 };
+enum { ORC_ISECT_BRUTE = 0, ORC_ISECT_BVH = 1 };
+enum { ORC_FORM_ITERATIVE = 0, ORC_FORM_RECURSIVE = 1 };
+
+#define ORC_INVALID_ID 0xFFFFFFFFu
+#define ORC_ACCUM_PLANES 22
+#define ORC_RESOLVE_PLANES 15
+
+/* material/mod.rs:98-101,133-137,315-318,369-372 as a tagged POD */
+typedef struct {
+    uint32_t kind;
+    float rgb[3]; /* albedo (diffuse) or le (emit) */
+    float ior;
+    float roughness;
+    uint32_t pad[2];
+} orc_material;
+
+/* ray.rs:8-12 */
+typedef struct {
+    float org[3];
+    float tnear;
+    float dir[3];
+    float tfar;
+} orc_ray;
+
+/* shape/mod.rs:22-41 plus the ids Embree reports; miss: geom_id == ORC_INVALID_ID, t = +inf */
+typedef struct {
+    float t;
+    float pos[3];
+    float n[3];
+    float uv[2];
+    uint32_t geom_id;
+    uint32_t prim_id;
+    uint32_t mat_id;
+} orc_hit;
+
+/* camera.rs:9-32 after Camera::new */
+typedef struct {
+    uint32_t width, height;
+    float half_width, half_height; /* viewport_half_width / _height */
+    float focal_length;
+    float aperture;
+    float lens[3];
+    float rot[4]; /* quaternion x,y,z,w */
+} orc_camera;
+
+/* executor.rs:46-58 + utils/mod.rs:89-109 */
+typedef struct {
+    uint32_t spp;          /* --spp: sets the strata count floor(sqrt(spp))^2 */
+    uint32_t sample_begin; /* --sample-range */
+    uint32_t sample_end;
+    uint32_t max_depth;
+    uint32_t integrator;
+    uint32_t isect_mode; /* ORC_ISECT_* */
+    uint32_t form;       /* ORC_FORM_* (path tracer only) */
+    uint32_t threads;    /* 0 = OpenMP default */
+    uint64_t seed;
+} orc_render_params;
+
+/* tile.rs:4-9 */
+typedef struct {
+    uint32_t x_start, x_end, y_start, y_end;
+} orc_tile;
+
+typedef struct orc_scene orc_scene;
+
+orc_scene *orc_scene_new(void);
+void orc_scene_free(orc_scene *s);
+uint32_t orc_scene_insert_material(orc_scene *s, const orc_material *m);
+void orc_scene_insert_light(orc_scene *s, const float pos[3]);
+uint32_t orc_scene_insert_mesh(orc_scene *s, uint32_t material, const float *vertices, size_t n_vertices,
+                               const uint32_t *indices, size_t n_triangles);
+uint32_t orc_scene_insert_sphere(orc_scene *s, uint32_t material, const float center[3], float radius);
+int orc_scene_commit(orc_scene *s);
+void orc_scene_bounds(const orc_scene *s, float lo[3], float hi[3]);
+size_t orc_scene_prim_count(const orc_scene *s);
+
+void orc_intersect(const orc_scene *s, const orc_ray *rays, orc_hit *hits, size_t n, int mode);
+
+/* Renders samples [sample_begin, sample_end) of the listed pixels (xy = x0,y0,x1,y1,...) and ADDS them to
+ * accum, laid out accum[plane * n_pixels + i].  Planes: 0-2 sum c, 3-5 sum c^2, 6-8 sum w*c, 9 sum w,
+ * 10-12 sum normal, 13-15 sum position, 16-18 sum albedo, 19 sum z, 20 sum ray_depth, 21 sample count.
+ * Returns the number of rays traced (closest-hit queries), bounces included. */
+uint64_t orc_render(const orc_scene *s, const orc_camera *cam, const orc_render_params *p, const uint32_t *xy,
+                    size_t n_pixels, float *accum);
+
+/* One sample: out[0..2] color, [3..5] normal, [6..8] position, [9..11] albedo, [12] z, [13] ray_depth,
+ * [14] samples_accumulated.  Returns rays traced. */
+uint32_t orc_render_sample(const orc_scene *s, const orc_camera *cam, const orc_render_params *p, uint32_t x,
+                           uint32_t y, uint32_t sample, float out[15]);
+
+/* renderer.rs:37-61: out[plane * n_pixels + i], planes Normal 0-2, Position 3-5, Albedo 6-8, Color 9-11,
+ * Variance 12, Z 13, RayDepth 14.  srgb != 0 applies output/mod.rs:46-51 (sRGB OETF on the four RGB channels). */
+void orc_resolve(const float *accum, size_t n_pixels, float *out, int srgb);
+
+/* tile.rs:69-97 */
+uint32_t orc_tile_count(uint32_t width, uint32_t height, uint32_t grain);
+int orc_tile_get(uint32_t offset_x, uint32_t offset_y, uint32_t width, uint32_t height, uint32_t grain, uint32_t idx,
+                 orc_tile *out);
+
+/* building blocks exposed for known-answer tests */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_uniform4(uint64_t seed, uint32_t x, uint32_t y, uint32_t sample, uint32_t stream, float out[4]);
+void orc_sincos_2pi(float u, float *s, float *c);
+void orc_frame(const float n[3], float cols[9]);
+int orc_bsdf_sample(const orc_material *m, const float n[3], const float wo[3], const float u[3], float wi[3],
+                    float f[3], float *pdf);
+void orc_bsdf_f(const orc_material *m, const float n[3], const float wo[3], const float wi[3], float f[3]);
+float orc_fresnel_dielectric(float cosi, float ior);
+int orc_refract(const float w[3], const float n[3], float ior, float out[3], float *ior_out);
+void orc_camera_ray(const orc_camera *cam, const orc_render_params *p, uint32_t x, uint32_t y, uint32_t sample,
+                    orc_ray *ray);
+int orc_ray_triangle(const orc_ray *ray, const float v0[3], const float v1[3], const float v2[3], float *t, float *u,
+                     float *v);
+int orc_ray_sphere(const orc_ray *ray, const float center[3], float radius, float *t, float ng[3]);
+int orc_slab_test(const float lo[3], const float hi[3], const orc_ray *ray, float *t0, float *t1);
+float orc_srgb_from_linear(float linear);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
