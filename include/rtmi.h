@@ -1,0 +1,222 @@
+/*
+ * rtmi.h -- C ABI of the MI355X path-tracing core.
+ *
+ * One shared library (librtmi.so, HIP/gfx950) replaces the reference's only accelerator back end: the Embree-backed
+ * scene (crates/rt/src/aggregate/embree.rs) and the CPU tile executor that drives it
+ * (crates/rt-cli/src/executor.rs).  Every entry point names the reference interface it stands in for.  All
+ * compute runs on the GPU; there is no CPU fallback, and every call fails with RTMI_ERR_DEVICE when no device is
+ * usable.
+ *
+ * Conventions
+ *   - Plain C types only.  Handles are opaque and owned by the caller; release them with the matching *_destroy.
+ *   - Input arrays are borrowed for the duration of the call and copied (as embree.rs:214-241 copies into
+ *     Embree-owned buffers).  Output arrays are caller-allocated.
+ *   - Functions returning int return RTMI_OK (0) or a negative RTMI_ERR_*; rtmi_last_error() then gives a
+ *     message for the calling thread.  No exception crosses this boundary.  (The reference panics on geometry
+ *     errors, embree.rs:190-248, and returns anyhow::Result from commit, embree.rs:63-69; a binding maps non-zero
+ *     to those.)
+ *   - insert_* / load_obj / commit on one scene must not run concurrently (the reference takes &mut self).
+ *     Queries and renders on a committed scene may be issued from several threads; they serialise per device.
+ *   - A scene is immutable once committed (the reference enforces it by borrow, embree.rs:81-84); inserting
+ *     after commit returns RTMI_ERR_STATE.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_OK 0
+#define RTMI_ERR_ARG (-1)    /* bad argument */
+#define RTMI_ERR_DEVICE (-2) /* no usable HIP device, or a HIP call failed */
+#define RTMI_ERR_STATE (-3)  /* call not valid in the object's state (e.g. insert after commit) */
+#define RTMI_ERR_IO (-4)     /* file could not be read or parsed */
+#define RTMI_ERR_CANCELLED (-5) /* the commit progress callback returned 0 */
+#define RTMI_ERR_LIMIT (-6)  /* a size exceeds what the kernels support */
+
+#define RTMI_INVALID_ID 0xFFFFFFFFu
+
+/* BxDF kinds: crates/rt/src/material/mod.rs:98-101 (Diffuse), :133-137 (Dielectric), :315-318 (ThinDielectric),
+ * :369-372 (Emit). */
+enum { RTMI_MAT_DIFFUSE = 0, RTMI_MAT_DIELECTRIC = 1, RTMI_MAT_THIN_DIELECTRIC = 2, RTMI_MAT_EMIT = 3 };
+
+/* crates/rt-cli/src/utils/mod.rs:140-155: `-i path-tracer` (default) / `-i basic`. */
+enum { RTMI_INTEGRATOR_PATH_TRACER = 0, RTMI_INTEGRATOR_RANDOM_WALK = 1 };
+
+/* MaterialDescriptor's BxDF as a tagged POD (material/mod.rs:401-404). rgb = albedo (Diffuse) or le (Emit). */
+typedef struct rtmi_material {
+    uint32_t kind;
+    float rgb[3];
+    float ior;
+    float roughness;
+    uint32_t pad[2];
+} rtmi_material;
+
+/* Ray, crates/rt/src/ray.rs:8-12; the layout Embree's RTCRay starts with (embree.rs:102-112). */
+typedef struct rtmi_ray {
+    float org[3];
+    float tnear;
+    float dir[3];
+    float tfar;
+} rtmi_ray;
+
+/* RayIntersection<local_info::Full>, crates/rt/src/shape/mod.rs:22-41, plus the ids Embree reports
+ * (embree.rs:129-135).  A miss has geom_id == prim_id == RTMI_INVALID_ID, t = +inf, everything else 0. */
+typedef struct rtmi_hit {
+    float t;
+    float pos[3];
+    float n[3];
+    float uv[2];
+    uint32_t geom_id;
+    uint32_t prim_id;
+    uint32_t mat_id;
+} rtmi_hit;
+
+/* Camera after Camera::new, crates/rt/src/camera.rs:9-57. rot is a quaternion (x, y, z, w). */
+typedef struct rtmi_camera {
+    uint32_t width, height;
+    float half_width, half_height;
+    float focal_length;
+    float aperture;
+    float lens[3];
+    float rot[4];
+} rtmi_camera;
+
+/* Transform, crates/rt/src/math/transform.rs:6-10. */
+typedef struct rtmi_transform {
+    float translation[3];
+    float scale[3];
+    float rot[4];
+} rtmi_transform;
+
+/* What Executor carries (crates/rt-cli/src/executor.rs:46-58) plus the sample range (utils/mod.rs:89-97). */
+typedef struct rtmi_render_params {
+    uint32_t spp;          /* --spp: fixes the strata grid floor(sqrt(spp))^2 (executor.rs:218) */
+    uint32_t sample_begin; /* --sample-range, half open */
+    uint32_t sample_end;
+    uint32_t max_depth;    /* --max-ray-depth (64, utils/mod.rs:149) */
+    uint32_t integrator;   /* RTMI_INTEGRATOR_* */
+    uint32_t samples_per_pass; /* samples of every pixel traced together; 0 = library default */
+    uint64_t seed;         /* --seed */
+} rtmi_render_params;
+
+typedef struct rtmi_render_stats {
+    uint64_t rays;   /* closest-hit queries traced, bounces included */
+    uint64_t paths;  /* camera samples started */
+    uint32_t passes; /* wavefront passes run */
+    uint32_t max_bounces; /* deepest bounce that still had live paths */
+    float gpu_ms;    /* device time of the call, from HIP events on the render stream */
+    float bounce_ms; /* device time spent in the bounce kernel alone */
+} rtmi_render_stats;
+
+typedef struct rtmi_scene_info {
+    uint64_t n_prims;
+    uint64_t n_nodes;
+    uint64_t node_bytes;
+    uint64_t prim_bytes;
+    uint32_t n_geoms;
+    uint32_t n_materials;
+    uint32_t stack_need; /* traversal stack entries the committed tree can require */
+    uint32_t max_depth;  /* depth of the wide tree */
+    float build_ms;      /* host time of commit (tree build + flatten + upload) */
+    float sah_cost;
+} rtmi_scene_info;
+
+typedef struct rtmi_device rtmi_device;
+typedef struct rtmi_scene rtmi_scene;
+typedef struct rtmi_film rtmi_film;
+
+const char *rtmi_last_error(void);
+const char *rtmi_version(void);
+
+/* embree4_rs Device::try_new (crates/rt-cli/src/main.rs:74-90).  hip_ordinal < 0 selects the current device. */
+int rtmi_device_create(int hip_ordinal, rtmi_device **out);
+void rtmi_device_destroy(rtmi_device *dev);
+
+/* The stream the library launches on (a hipStream_t), for callers that time or order work against it. */
+void *rtmi_device_stream(rtmi_device *dev);
+/* Work counters the reference does not have (its only counter is utils/counter.rs:84-102): when enabled, every
+ * render adds its BVH node fetches to out[0] and its primitive tests to out[1].  Enabling resets both. */
+int rtmi_device_count_visits(rtmi_device *dev, int enable);
+int rtmi_device_get_visits(rtmi_device *dev, uint64_t out[2]);
+
+/* EmbreeScene::new (embree.rs:29-51): material 0 is the black "Sky" diffuse. */
+int rtmi_scene_create(rtmi_device *dev, rtmi_scene **out);
+void rtmi_scene_destroy(rtmi_scene *scene);
+
+/* SceneT::insert_material (scene/mod.rs:11, embree.rs:167-171): returns the MaterialId in *out_id. */
+int rtmi_scene_insert_material(rtmi_scene *scene, const rtmi_material *mat, uint32_t *out_id);
+/* SceneT::insert_light (scene/mod.rs:12, embree.rs:173-175): stored; no integrator reads lights. */
+int rtmi_scene_insert_light(rtmi_scene *scene, const float pos[3]);
+/* SceneT::insert_mesh (scene/mod.rs:13-18, embree.rs:177-253): vertices = n_vertices x 3 floats, indices =
+ * n_triangles x 3 uint32; returns the GeometryHandle (geometry id) in *out_geom. */
+int rtmi_scene_insert_mesh(rtmi_scene *scene, uint32_t material, const float *vertices, size_t n_vertices,
+                           const uint32_t *indices, size_t n_triangles, uint32_t *out_geom);
+/* SceneT::insert_sphere (scene/mod.rs:20-25, embree.rs:255-265). */
+int rtmi_scene_insert_sphere(rtmi_scene *scene, uint32_t material, const float center[3], float radius,
+                             uint32_t *out_geom);
+/* ObjLoaderExt::load_obj (crates/rt/src/loader/obj.rs:24-123): OBJ + MTL read with tobj's GPU_LOAD_OPTIONS +
+ * single_index semantics; every MTL material becomes a Diffuse(Kd); one mesh per model; transform applied to the
+ * positions.  *out_first_geom / *out_n_geoms (either may be NULL) receive the range of geometry ids inserted. */
+int rtmi_scene_load_obj(rtmi_scene *scene, const char *path, const rtmi_transform *transform,
+                        uint32_t default_material, uint32_t *out_first_geom, uint32_t *out_n_geoms);
+
+/* EmbreeScene::commit / commit_with_progress (embree.rs:63-78): builds the SAH BVH on the host, flattens it to
+ * the 4-wide GPU node / 48-byte primitive layout and uploads it.  progress (may be NULL) is called with values
+ * in [0,1]; returning 0 cancels (RTMI_ERR_CANCELLED). */
+typedef int (*rtmi_progress_fn)(double amount, void *user);
+int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user);
+
+/* Shape::bounding_box (shape/mod.rs:8, embree.rs:146-161). */
+int rtmi_scene_bounds(const rtmi_scene *scene, float lo[3], float hi[3]);
+int rtmi_scene_get_info(const rtmi_scene *scene, rtmi_scene_info *out);
+/* geometry_material map (embree.rs:24,53-61): material of a geometry id. */
+int rtmi_scene_geometry_material(const rtmi_scene *scene, uint32_t geom, uint32_t *out_material);
+
+/* Shape::intersection_full (shape/mod.rs:4, embree.rs:101-140) for n rays at once: closest hit in
+ * (tnear, tfar].  Host arrays; the rays are copied to the GPU, traced there and the hits copied back. */
+int rtmi_intersect(rtmi_scene *scene, const rtmi_ray *rays, rtmi_hit *hits, size_t n);
+/* Same with device-resident arrays, asynchronous on hip_stream (a hipStream_t; NULL = the default stream). */
+int rtmi_intersect_device(rtmi_scene *scene, const rtmi_ray *d_rays, rtmi_hit *d_hits, size_t n, void *hip_stream);
+
+/* The per-pixel accumulators the executor keeps (Dispatcher::tiles_data, executor.rs:177-205; RaySeries,
+ * crates/rt/src/renderer.rs:24-34) for an explicit list of pixels: xy = n_pixels x (x, y) uint32, host array.
+ * Accumulators live on the GPU as RTMI_ACCUM_PLANES planes of n_pixels floats, plane-major:
+ *   0-2 sum c, 3-5 sum c^2, 6-8 sum w*c, 9 sum w, 10-12 sum normal, 13-15 sum position, 16-18 sum albedo,
+ *   19 sum z, 20 sum ray_depth, 21 samples accumulated.
+ * d_accum may be a caller-owned device buffer of RTMI_ACCUM_PLANES * n_pixels floats (it is used in place and
+ * must outlive the film), or NULL to let the film allocate (and zero) its own. */
+#define RTMI_ACCUM_PLANES 22
+#define RTMI_RESOLVE_PLANES 15
+int rtmi_film_create(rtmi_device *dev, const uint32_t *xy, size_t n_pixels, float *d_accum, rtmi_film **out);
+void rtmi_film_destroy(rtmi_film *film);
+int rtmi_film_clear(rtmi_film *film);
+/* Device pointer of the accumulator planes. */
+float *rtmi_film_accum_device(rtmi_film *film);
+/* Copies the accumulator planes to the host (RTMI_ACCUM_PLANES * n_pixels floats). */
+int rtmi_film_download(rtmi_film *film, float *accum);
+/* RaySeries::as_pixelresult (renderer.rs:37-61) on the GPU: out = RTMI_RESOLVE_PLANES planes of n_pixels floats
+ * on the host: Normal 0-2, Position 3-5, Albedo 6-8, Color 9-11, Variance 12, Z 13, RayDepth 14.  srgb != 0 also
+ * applies OutputBuffers::convert (crates/rt-cli/src/output/mod.rs:46-58): sRGB OETF on the four RGB channels. */
+int rtmi_film_resolve(rtmi_film *film, float *out, int srgb);
+
+/* Executor::run_* + tile_worker + pixel_worker (executor.rs:77-270) for the film's pixels: traces samples
+ * [sample_begin, sample_end) of every pixel through the wavefront pipeline (camera ray, then per bounce: closest
+ * hit, shade, compact) and adds them to the film (RaySeries::add_sample, renderer.rs:63-82).  Synchronous.
+ * stats may be NULL. */
+int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, const rtmi_render_params *params,
+                rtmi_render_stats *stats);
+
+/* Tiler::tile_count / Tiler::tile (crates/rt-cli/src/tile.rs:69-97). out = x_start, x_end, y_start, y_end. */
+uint32_t rtmi_tile_count(uint32_t width, uint32_t height, uint32_t grain);
+int rtmi_tile_get(uint32_t offset_x, uint32_t offset_y, uint32_t width, uint32_t height, uint32_t grain,
+                  uint32_t idx, uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

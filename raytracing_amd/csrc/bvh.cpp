@@ -1,0 +1,312 @@
+// bvh.cpp -- binned-SAH BVH2 build (multi-threaded over subtrees), collapse to BVH4, breadth-first flatten.
+#include "bvh.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+namespace rtb {
+
+namespace {
+
+constexpr int BINS = 16;
+constexpr uint32_t LEAF_MAX = 4;
+constexpr uint32_t PARALLEL_MIN = 32768; // subtrees at least this large may get their own thread
+
+struct Node2 {
+    Box box;
+    uint32_t left = 0, right = 0; // children (inner)
+    uint32_t first = 0, count = 0; // leaf range in order[] (count > 0 = leaf)
+};
+
+inline void box_init(Box &b) {
+    for (int a = 0; a < 3; ++a) {
+        b.lo[a] = INFINITY;
+        b.hi[a] = -INFINITY;
+    }
+}
+inline void box_grow(Box &b, const Box &o) {
+    for (int a = 0; a < 3; ++a) {
+        b.lo[a] = fminf(b.lo[a], o.lo[a]);
+        b.hi[a] = fmaxf(b.hi[a], o.hi[a]);
+    }
+}
+inline float half_area(const Box &b) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    if (!(dx >= 0.0f) || !(dy >= 0.0f) || !(dz >= 0.0f)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+struct Builder {
+    const std::vector<Box> &boxes;
+    std::vector<float> cen; // 3 per primitive
+    std::vector<uint32_t> order;
+    std::vector<Node2> nodes;
+    std::atomic<int> live{1};
+    int max_threads = 1;
+    std::atomic<size_t> done{0};
+    std::atomic<bool> cancelled{false};
+
+    explicit Builder(const std::vector<Box> &b) : boxes(b) {}
+
+    // Subtree over order[begin, end) rooted at node slot `slot`; it owns slots [slot, slot + 2 * (end - begin) - 1).
+    void build(uint32_t slot, uint32_t begin, uint32_t end) {
+        Node2 &n = nodes[slot];
+        Box bb, cb;
+        box_init(bb);
+        box_init(cb);
+        for (uint32_t i = begin; i < end; ++i) {
+            const uint32_t p = order[i];
+            box_grow(bb, boxes[p]);
+            for (int a = 0; a < 3; ++a) {
+                cb.lo[a] = fminf(cb.lo[a], cen[3 * (size_t)p + a]);
+                cb.hi[a] = fmaxf(cb.hi[a], cen[3 * (size_t)p + a]);
+            }
+        }
+        n.box = bb;
+        const uint32_t count = end - begin;
+        if (count <= LEAF_MAX) {
+            n.first = begin;
+            n.count = count;
+            done.fetch_add(count, std::memory_order_relaxed);
+            return;
+        }
+        // bin on all three axes, keep the cheapest split
+        Box bins[3][BINS];
+        uint32_t bcnt[3][BINS];
+        float scale[3];
+        for (int a = 0; a < 3; ++a) {
+            const float ext = cb.hi[a] - cb.lo[a];
+            scale[a] = ext > 0.0f ? (float)BINS / ext : 0.0f;
+            for (int b = 0; b < BINS; ++b) {
+                box_init(bins[a][b]);
+                bcnt[a][b] = 0;
+            }
+        }
+        auto bin_of = [&](uint32_t p, int a) {
+            int b = (int)((cen[3 * (size_t)p + a] - cb.lo[a]) * scale[a]);
+            return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+        };
+        for (uint32_t i = begin; i < end; ++i) {
+            const uint32_t p = order[i];
+            for (int a = 0; a < 3; ++a) {
+                if (scale[a] == 0.0f) continue;
+                const int b = bin_of(p, a);
+                bcnt[a][b]++;
+                box_grow(bins[a][b], boxes[p]);
+            }
+        }
+        float best = INFINITY;
+        int best_axis = -1, best_bin = -1;
+        for (int a = 0; a < 3; ++a) {
+            if (scale[a] == 0.0f) continue;
+            float rarea[BINS];
+            uint32_t rcnt[BINS];
+            Box r;
+            box_init(r);
+            uint32_t rc = 0;
+            for (int b = BINS - 1; b > 0; --b) {
+                box_grow(r, bins[a][b]);
+                rc += bcnt[a][b];
+                rarea[b] = half_area(r);
+                rcnt[b] = rc;
+            }
+            Box l;
+            box_init(l);
+            uint32_t lc = 0;
+            for (int b = 0; b < BINS - 1; ++b) {
+                box_grow(l, bins[a][b]);
+                lc += bcnt[a][b];
+                if (lc == 0 || rcnt[b + 1] == 0) continue;
+                const float cost = half_area(l) * (float)lc + rarea[b + 1] * (float)rcnt[b + 1];
+                if (cost < best) {
+                    best = cost;
+                    best_axis = a;
+                    best_bin = b;
+                }
+            }
+        }
+        uint32_t mid = begin + count / 2;
+        if (best_axis >= 0) {
+            uint32_t i = begin, j = end;
+            while (i < j) {
+                const uint32_t p = order[i];
+                if (bin_of(p, best_axis) <= best_bin) {
+                    ++i;
+                } else {
+                    --j;
+                    order[i] = order[j];
+                    order[j] = p;
+                }
+            }
+            if (i > begin && i < end) mid = i;
+        }
+        const uint32_t nl = mid - begin;
+        const uint32_t ls = slot + 1, rs = slot + 2 * nl;
+        n.left = ls;
+        n.right = rs;
+        n.count = 0;
+        if (cancelled.load(std::memory_order_relaxed)) return;
+        bool spawned = false;
+        std::thread worker;
+        if (nl >= PARALLEL_MIN && (end - mid) >= PARALLEL_MIN) {
+            int cur = live.load();
+            while (cur < max_threads && !live.compare_exchange_weak(cur, cur + 1)) {
+            }
+            if (cur < max_threads) {
+                spawned = true;
+                worker = std::thread([this, ls, begin, mid] {
+                    build(ls, begin, mid);
+                    live.fetch_sub(1);
+                });
+            }
+        }
+        if (!spawned) build(ls, begin, mid);
+        build(rs, mid, end);
+        if (spawned) worker.join();
+    }
+};
+
+} // namespace
+
+bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool(double)> &progress, unsigned threads) {
+    out = WideBvh();
+    const size_t n = boxes.size();
+    if (progress && !progress(0.0)) return false;
+    if (n == 0) {
+        if (progress) progress(1.0);
+        return true;
+    }
+    Builder b(boxes);
+    b.cen.resize(3 * n);
+    b.order.resize(n);
+    b.nodes.resize(2 * n);
+    for (size_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) b.cen[3 * i + a] = 0.5f * boxes[i].lo[a] + 0.5f * boxes[i].hi[a];
+        b.order[i] = (uint32_t)i;
+    }
+    unsigned hw = threads ? threads : std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    if (hw > 16) hw = 16;
+    b.max_threads = (int)hw;
+
+    // run the build on a worker so that this thread can report progress
+    std::atomic<bool> finished{false};
+    std::thread root([&] {
+        b.build(0, 0, (uint32_t)n);
+        finished.store(true);
+    });
+    bool ok = true;
+    while (!finished.load()) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(n > 100000 ? 20 : 1));
+        if (progress && ok && !progress(0.8 * (double)b.done.load() / (double)n)) {
+            ok = false;
+            b.cancelled.store(true);
+        }
+    }
+    root.join();
+    if (!ok) return false;
+
+    // collapse to 4-wide, breadth-first
+    const std::vector<Node2> &N2 = b.nodes;
+    std::vector<uint32_t> wide_root; // node2 index each wide node expands
+    wide_root.push_back(0);
+    std::vector<rtd::F4> &W = out.nodes;
+    std::vector<uint8_t> nchild;
+    std::vector<uint32_t> child_ref; // 4 per wide node
+    const float root_area = half_area(N2[0].box);
+    double sah = 0.0;
+    for (size_t w = 0; w < wide_root.size(); ++w) {
+        const Node2 &r = N2[wide_root[w]];
+        uint32_t ch[4];
+        int nc = 0;
+        if (r.count > 0) {
+            ch[nc++] = wide_root[w]; // a root that is itself a leaf
+        } else {
+            ch[nc++] = r.left;
+            ch[nc++] = r.right;
+            while (nc < 4) {
+                int pick = -1;
+                float best_area = -1.0f;
+                for (int k = 0; k < nc; ++k) {
+                    if (N2[ch[k]].count > 0) continue;
+                    const float ar = half_area(N2[ch[k]].box);
+                    if (ar > best_area) {
+                        best_area = ar;
+                        pick = k;
+                    }
+                }
+                if (pick < 0) break;
+                const uint32_t c = ch[pick];
+                for (int k = nc; k > pick + 1; --k) ch[k] = ch[k - 1];
+                ch[pick] = N2[c].left;
+                ch[pick + 1] = N2[c].right;
+                ++nc;
+            }
+        }
+        rtd::F4 slots[rtd::RT_NODE_F4];
+        float *f = reinterpret_cast<float *>(slots);
+        uint32_t refs[4];
+        for (int k = 0; k < 4; ++k) {
+            if (k < nc) {
+                const Node2 &c = N2[ch[k]];
+                for (int a = 0; a < 3; ++a) {
+                    f[4 * a + k] = c.box.lo[a];
+                    f[4 * (3 + a) + k] = c.box.hi[a];
+                }
+                if (c.count > 0) {
+                    refs[k] = rtd::RT_LEAF | ((c.count - 1u) << 28) | c.first;
+                    if (root_area > 0.0f) sah += (double)half_area(c.box) / root_area * c.count;
+                } else {
+                    refs[k] = (uint32_t)wide_root.size();
+                    wide_root.push_back(ch[k]);
+                    if (root_area > 0.0f) sah += (double)half_area(c.box) / root_area;
+                }
+            } else {
+                for (int a = 0; a < 3; ++a) {
+                    f[4 * a + k] = INFINITY;
+                    f[4 * (3 + a) + k] = -INFINITY;
+                }
+                refs[k] = rtd::RT_EMPTY;
+            }
+        }
+        memcpy(&f[24], refs, sizeof refs);
+        for (int k = 28; k < 32; ++k) f[k] = 0.0f;
+        for (int k = 0; k < rtd::RT_NODE_F4; ++k) W.push_back(slots[k]);
+        nchild.push_back((uint8_t)nc);
+        for (int k = 0; k < 4; ++k) child_ref.push_back(refs[k]);
+        if (progress && (w & 0xFFFF) == 0 && !progress(0.8 + 0.1 * (double)w / (double)(wide_root.size() + 1)))
+            return false;
+    }
+    out.n_nodes = (uint32_t)wide_root.size();
+    out.sah_cost = (float)sah;
+    out.prim_order = std::move(b.order);
+
+    // worst-case stack need and depth: children always have larger indices than their parent
+    std::vector<uint32_t> need(out.n_nodes, 0), depth(out.n_nodes, 1);
+    for (size_t w = out.n_nodes; w-- > 0;) {
+        uint32_t nd = 0, dp = 1;
+        const uint32_t nc = nchild[w];
+        for (uint32_t k = 0; k < nc; ++k) {
+            const uint32_t ref = child_ref[4 * w + k];
+            uint32_t cn = 0, cd = 0;
+            if (!(ref & rtd::RT_LEAF)) {
+                cn = need[ref];
+                cd = depth[ref];
+            }
+            nd = std::max(nd, (nc - 1) + cn);
+            dp = std::max(dp, 1 + cd);
+        }
+        need[w] = nd;
+        depth[w] = dp;
+    }
+    out.stack_need = need[0];
+    out.depth = depth[0];
+    if (progress && !progress(0.9)) return false;
+    return true;
+}
+
+} // namespace rtb

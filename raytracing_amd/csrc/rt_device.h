@@ -1,0 +1,735 @@
+// rt_device.h -- per-ray device code of the path-tracing kernels: closest-hit traversal of the flattened 4-wide
+// BVH, Moeller-Trumbore / sphere tests, counter-based RNG, camera rays, BSDF sampling and the per-bounce shading
+// step.  Every function is straight-line f32 arithmetic in a fixed operation order (build with
+// -ffp-contract=off), so a path's result does not depend on which lane, wave or device evaluates it.
+//
+// Reference behaviour reproduced here (paths relative to the reference checkout):
+//   closest hit contract   crates/rt/src/aggregate/embree.rs:100-140
+//   path tracer            crates/rt/src/integrators/pathtracing.rs:21-79, integrators/mod.rs:8-23
+//   random walk            crates/rt/src/integrators/randomwalk.rs:24-68
+//   BSDF / BxDFs           crates/rt/src/material/mod.rs:56-394
+//   distributions          crates/rt/src/math/distributions.rs:86-95,120-130,176-265
+//   frame                  crates/rt/src/math/transform.rs:63-94
+//   reflect / refract      crates/rt/src/math/vec.rs:14-52
+//   camera                 crates/rt/src/camera.rs:62-107
+//   sampler / filter       crates/rt/src/sampler.rs:91-102, crates/rt/src/filter.rs:23-32
+//   pixel driver           crates/rt-cli/src/executor.rs:254-270
+//
+// RT_DEV is `__device__ __forceinline__` in the kernels.  A host debugging build may define it as `inline` to
+// single-step the same code under gdb; no shipped code path does.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#ifndef RT_DEV
+#define RT_DEV __device__ __forceinline__
+#endif
+
+namespace rtd {
+
+// ---------------------------------------------------------------------------------------------- layout
+
+// 128-byte BVH4 node: child boxes SoA (lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4]), child refs, padding.
+// Child ref: RT_EMPTY = unused slot; bit 31 set = leaf: bits 28..30 = prim count - 1, bits 0..27 = first prim slot;
+// otherwise the index of an inner node.
+struct alignas(16) F4 {
+    float x, y, z, w;
+};
+struct alignas(16) U4 {
+    uint32_t x, y, z, w;
+};
+constexpr uint32_t RT_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t RT_LEAF = 0x80000000u;
+constexpr uint32_t RT_SPHERE = 0x80000000u;
+constexpr int RT_NODE_F4 = 8; // float4s per node
+constexpr int RT_PRIM_F4 = 3; // float4s per primitive
+
+// 48-byte primitive: triangle = v0.xyz, e1.xyz (v1 - v0), e2.xyz (v2 - v0); sphere = centre.xyz, radius.
+// Words 9..11: global primitive index (insertion order), geometry id | RT_SPHERE, primitive id inside the geometry.
+
+struct Material {
+    uint32_t kind;
+    float r, g, b;
+    float ior;
+    float roughness;
+    uint32_t pad0, pad1;
+};
+constexpr uint32_t MAT_DIFFUSE = 0, MAT_DIELECTRIC = 1, MAT_THIN = 2, MAT_EMIT = 3;
+
+struct SceneView {
+    const F4 *nodes;
+    const F4 *prims;
+    const uint32_t *geom_material;
+    const Material *materials;
+    uint32_t n_nodes;
+    uint32_t n_prims;
+    uint32_t n_geoms;
+    uint32_t n_materials;
+};
+
+struct CameraView {
+    uint32_t width, height;
+    float half_width, half_height, focal_length, aperture;
+    float lens[3];
+    float rot[4];
+};
+
+// ---------------------------------------------------------------------------------------------- vectors
+
+struct V3 {
+    float x, y, z;
+};
+RT_DEV V3 mk(float x, float y, float z) {
+    V3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+RT_DEV V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV V3 scale(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+RT_DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_DEV V3 cross(V3 a, V3 b) { return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+RT_DEV V3 normalize(V3 a) {
+    float rcp = 1.0f / sqrtf(dot(a, a));
+    return mk(a.x * rcp, a.y * rcp, a.z * rcp);
+}
+RT_DEV V3 normalize_or_zero(V3 a) {
+    float rcp = 1.0f / sqrtf(dot(a, a));
+    if (isfinite(rcp) && rcp > 0.0f) return mk(a.x * rcp, a.y * rcp, a.z * rcp);
+    return mk(0.0f, 0.0f, 0.0f);
+}
+RT_DEV float max_element(V3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+
+constexpr float RT_PI = 3.14159265358979323846f;
+constexpr float RT_FRAC_1_PI = 0.318309886183790671538f;
+constexpr float RT_TNEAR = 0.00001f; // pathtracing.rs:29
+
+// ---------------------------------------------------------------------------------------------- RNG
+
+// Philox4x32-10 keyed by the 64-bit seed; counter = (x, y, sample, stream).  stream 0 = camera sample,
+// stream 1 + d = bounce d.  Floats are the top 23 bits as k * 2^-23 (rand 0.8.5's Uniform<f32>(0, 1)).
+RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+RT_DEV void uniform4(uint64_t seed, uint32_t x, uint32_t y, uint32_t sample, uint32_t stream, float u[4]) {
+    uint32_t r[4];
+    philox4x32_10(x, y, sample, stream, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = (float)(r[i] >> 9) * 1.1920928955078125e-07f;
+}
+
+// sin(2 pi u), cos(2 pi u), u in [0,1): exact removal of the nearest quarter turn, then Taylor polynomials in
+// x = 2 pi r (|x| <= pi/4) by Horner in plain multiply/add.
+RT_DEV void sincos_2pi(float u, float &s, float &c) {
+    float qf = floorf(u * 4.0f + 0.5f);
+    float r = u - qf * 0.25f;
+    float x = 6.28318530717958647692f * r;
+    float x2 = x * x;
+    float sp = x * (1.0f + x2 * (-1.66666666666666666667e-01f +
+                                 x2 * (8.33333333333333333333e-03f +
+                                       x2 * (-1.98412698412698412698e-04f + x2 * 2.75573192239858906526e-06f))));
+    float cp = 1.0f + x2 * (-0.5f + x2 * (4.16666666666666666667e-02f +
+                                          x2 * (-1.38888888888888888889e-03f +
+                                                x2 * (2.48015873015873015873e-05f +
+                                                      x2 * -2.75573192239858906526e-07f))));
+    int q = (int)qf & 3;
+    if (q == 0) {
+        s = sp;
+        c = cp;
+    } else if (q == 1) {
+        s = cp;
+        c = -sp;
+    } else if (q == 2) {
+        s = -sp;
+        c = -cp;
+    } else {
+        s = -cp;
+        c = sp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- frame
+
+struct Frame {
+    V3 c0, c1, c2;
+};
+// transform.rs:63-86
+RT_DEV Frame frame_new(V3 n) {
+    float sign = copysignf(1.0f, n.z);
+    float a = -1.0f / (sign + n.z);
+    float b = n.x * n.y * a;
+    Frame f;
+    f.c0 = mk(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+    f.c1 = mk(b, sign + n.y * n.y * a, -n.y);
+    f.c2 = n;
+    return f;
+}
+RT_DEV V3 to_local(const Frame &f, V3 g) { return mk(dot(f.c0, g), dot(f.c1, g), dot(f.c2, g)); }
+RT_DEV V3 from_local(const Frame &f, V3 l) {
+    return mk((f.c0.x * l.x + f.c1.x * l.y) + f.c2.x * l.z, (f.c0.y * l.x + f.c1.y * l.y) + f.c2.y * l.z,
+              (f.c0.z * l.x + f.c1.z * l.y) + f.c2.z * l.z);
+}
+
+// ---------------------------------------------------------------------------------------------- sampling
+
+// distributions.rs:86-95
+RT_DEV void ball2(float u0, float u1, float &px, float &py) {
+    float s, c;
+    sincos_2pi(u0, s, c);
+    float r = sqrtf(u1);
+    px = r * c;
+    py = r * s;
+}
+// distributions.rs:176-188
+RT_DEV V3 cosine_hemisphere(float u0, float u1) {
+    float px, py;
+    ball2(u0, u1, px, py);
+    float z = sqrtf(1.0f - px * px - py * py);
+    return mk(px, py, z);
+}
+// distributions.rs:120-130 (theta = pi * u1 evaluated as 2 pi (u1 / 2))
+RT_DEV V3 uniform_unit_sphere3(float u0, float u1) {
+    float sphi, cphi, stheta, ctheta;
+    sincos_2pi(u0, sphi, cphi);
+    sincos_2pi(u1 * 0.5f, stheta, ctheta);
+    return mk(cphi * stheta, sphi * stheta, ctheta);
+}
+// float.rs:26-28
+RT_DEV float lerp_ext(float self, float from, float to) { return self * to + (1.0f - self) * from; }
+// vec.rs:16-18
+RT_DEV bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0.0f; }
+// vec.rs:27-29
+RT_DEV V3 reflect(V3 w, V3 n) { return add(neg(w), scale(2.0f * dot(w, n), n)); }
+// vec.rs:33-52
+RT_DEV bool refract(V3 w, V3 normal, float ior, V3 &out, float &ior_out) {
+    float cosi = dot(w, normal);
+    if (!(cosi >= 0.0f)) {
+        normal = neg(normal);
+        cosi = -cosi;
+        ior = 1.0f / ior;
+    }
+    float cost2 = 1.0f - fmaxf(0.0f, 1.0f - cosi * cosi) / ior / ior;
+    if (cost2 <= 0.0f) return false;
+    float cost = sqrtf(cost2);
+    V3 a = mk(-w.x / ior, -w.y / ior, -w.z / ior);
+    out = add(a, scale(cosi / ior - cost, normal));
+    ior_out = ior;
+    return true;
+}
+// material/mod.rs:139-154
+RT_DEV float fresnel_dielectric(float cosi, float ior) {
+    if (!(cosi >= 0.0f)) {
+        cosi = -cosi;
+        ior = 1.0f / ior;
+    }
+    float cost2 = 1.0f - (1.0f - cosi * cosi) / ior / ior;
+    if (cost2 < 0.0f) return 1.0f;
+    float cost = sqrtf(cost2);
+    float r_parl = (ior * cosi - cost) / (ior * cosi + cost);
+    float r_perp = (cosi - ior * cost) / (cosi + ior * cost);
+    return 0.5f * (r_parl * r_parl + r_perp * r_perp);
+}
+
+// distributions.rs:203-265; the normal distribution and the masking term are the reference's own variants.
+RT_DEV bool tr_is_smooth(float alpha) { return alpha < 1e-8f; }
+RT_DEV float tr_d(float alpha, V3 wm) {
+    float cos2 = wm.z * wm.z;
+    float sin2 = 1.0f - cos2;
+    float tan2 = sin2 / cos2;
+    float at = alpha + tan2;
+    return 1.0f / (RT_PI * (cos2 * cos2) * (at * at));
+}
+RT_DEV float tr_lambda(float alpha, V3 w) {
+    float cos2 = w.z * w.z;
+    float sin2 = 1.0f - cos2;
+    float tan2 = sin2 / cos2;
+    return sqrtf(1.0f + (alpha * alpha) * tan2) / 2.0f;
+}
+RT_DEV float tr_g(float alpha, V3 w0, V3 w1) { return 1.0f / (1.0f + tr_lambda(alpha, w0) + tr_lambda(alpha, w1)); }
+RT_DEV float tr_g1(float alpha, V3 w) { return 1.0f / (1.0f + tr_lambda(alpha, w)); }
+RT_DEV float tr_dw(float alpha, V3 w, V3 wm) {
+    return tr_g1(alpha, w) / fabsf(w.z) * tr_d(alpha, wm) * fabsf(dot(w, wm));
+}
+RT_DEV V3 tr_sample_wm(float alpha, V3 w, float u0, float u1) {
+    w = normalize(mk(alpha * w.x, alpha * w.y, w.z));
+    if (!(w.z >= 0.0f)) w = neg(w);
+    V3 t1 = (w.z < 0.9999f) ? normalize(cross(mk(0.0f, 0.0f, 1.0f), w)) : mk(1.0f, 0.0f, 0.0f);
+    V3 t2 = cross(w, t1);
+    float px, py;
+    ball2(u0, u1, px, py);
+    float h = sqrtf(1.0f - px * px);
+    py = lerp_ext((1.0f + w.z) / 2.0f, h, py);
+    float pz = sqrtf(fmaxf(0.0f, 1.0f - (px * px + py * py)));
+    V3 nh = add(add(scale(px, t1), scale(py, t2)), scale(pz, w));
+    return normalize(mk(alpha * nh.x, alpha * nh.y, fmaxf(1e-6f, nh.z)));
+}
+
+// ---------------------------------------------------------------------------------------------- BxDFs
+
+struct BxdfSample {
+    V3 wi;
+    V3 f;
+    float pdf;
+};
+RT_DEV V3 white(float s) { return mk(s * 1.0f, s * 1.0f, s * 1.0f); }
+
+// material/mod.rs:119-130
+RT_DEV bool diffuse_sample_f(const Material &m, V3 wo, float u0, float u1, BxdfSample &o) {
+    V3 wi = cosine_hemisphere(u0, u1);
+    wi.z = copysignf(wi.z, wo.z);
+    o.wi = wi;
+    o.f = mk(RT_FRAC_1_PI * m.r, RT_FRAC_1_PI * m.g, RT_FRAC_1_PI * m.b);
+    o.pdf = fabsf(wi.z) * RT_FRAC_1_PI;
+    return true;
+}
+
+// material/mod.rs:244-312
+RT_DEV bool dielectric_sample_f(const Material &m, V3 wo, float u0, float u1, float u2, BxdfSample &o) {
+    float alpha = m.roughness;
+    if (m.ior == 1.0f || tr_is_smooth(alpha)) {
+        float r = fresnel_dielectric(wo.z, m.ior);
+        float t = 1.0f - r;
+        if (u2 <= r / (r + t)) {
+            V3 wi = mk(-wo.x, -wo.y, wo.z);
+            o.wi = wi;
+            o.f = white(r / fabsf(wi.z));
+            o.pdf = r / (r + t);
+            return true;
+        }
+        V3 wi;
+        float ior2;
+        if (!refract(wo, mk(0.0f, 0.0f, 1.0f), m.ior, wi, ior2)) return false;
+        o.wi = wi;
+        o.f = white(t / fabsf(wi.z));
+        o.pdf = t / (r + t);
+        return true;
+    }
+    V3 wm = tr_sample_wm(alpha, wo, u0, u1);
+    float r = fresnel_dielectric(dot(wo, wm), m.ior);
+    float t = 1.0f - r;
+    if (u2 < r / (r + t)) {
+        V3 wi = reflect(wo, wm);
+        if (!same_hemisphere(wo, wi)) return false;
+        float f = tr_d(alpha, wm) * tr_g(alpha, wo, wi) * r / (4.0f * wi.z * wo.z);
+        float pdf = tr_dw(alpha, wo, wm) / (4.0f * fabsf(dot(wo, wm))) * r / (r + t);
+        o.wi = wi;
+        o.f = white(f);
+        o.pdf = pdf;
+        return true;
+    }
+    V3 wi;
+    float ior2;
+    if (!refract(wo, wm, m.ior, wi, ior2)) return false;
+    if (same_hemisphere(wi, wo) || wi.z == 0.0f) return false;
+    float s = dot(wi, wm) + dot(wo, wm) / ior2;
+    float denom = s * s;
+    float dwm_dwi = fabsf(dot(wi, wm)) / denom;
+    float f = t * tr_d(alpha, wm) * tr_g(alpha, wo, wi) * fabsf(dot(wo, wm) * dot(wi, wm) / (wi.z * wo.z * denom));
+    float pdf = tr_dw(alpha, wo, wm) * dwm_dwi * t / (r + t);
+    o.wi = wi;
+    o.f = white(f);
+    o.pdf = pdf;
+    return true;
+}
+
+// material/mod.rs:339-366
+RT_DEV bool thin_dielectric_sample_f(const Material &m, V3 wo, float u2, BxdfSample &o) {
+    float r = fresnel_dielectric(wo.z, m.ior);
+    float t = 1.0f - r;
+    if (r >= 1.0f) {
+        r = 1.0f;
+        t = 0.0f;
+    } else {
+        r = r + t * t * r / (1.0f - r * r);
+        t = 1.0f - r;
+    }
+    if (u2 <= r / (r + t)) {
+        V3 wi = mk(-wo.x, -wo.y, wo.z);
+        o.wi = wi;
+        o.f = white(r / fabsf(wi.z));
+        o.pdf = r / (r + t);
+    } else {
+        V3 wi = neg(wo);
+        o.wi = wi;
+        o.f = white(t / fabsf(wi.z));
+        o.pdf = t / (r + t);
+    }
+    return true;
+}
+
+// material/mod.rs:167-207 (evaluated only by the random-walk integrator)
+RT_DEV V3 dielectric_f(const Material &m, V3 wo, V3 wi) {
+    float alpha = m.roughness;
+    V3 black = mk(0.0f, 0.0f, 0.0f);
+    if (m.ior == 1.0f || tr_is_smooth(alpha)) return black;
+    float cosi = wi.z, coso = wo.z;
+    bool is_reflect = cosi * coso > 0.0f;
+    float ior = (is_reflect || coso > 0.0f) ? m.ior : 1.0f / m.ior;
+    V3 wm = add(scale(ior, wi), wo);
+    if (cosi == 0.0f || coso == 0.0f || dot(wm, wm) == 0.0f) return black;
+    float sg = isnan(wm.z) ? wm.z : copysignf(1.0f, wm.z);
+    wm = scale(sg, normalize(wm));
+    if (dot(wi, wm) * cosi < 0.0f || dot(wo, wm) * coso < 0.0f) return black;
+    float r = fresnel_dielectric(dot(wo, wm), ior);
+    float t = 1.0f - r;
+    if (is_reflect) return white(tr_d(alpha, wm) * tr_g(alpha, wo, wi) * r / fabsf(4.0f * cosi * coso));
+    float s = dot(wi, wm) + dot(wo, wm) / ior;
+    float denom = s * s * cosi * coso;
+    return white(tr_d(alpha, wm) * t * tr_g(alpha, wo, wi) * fabsf(dot(wi, wm) * dot(wo, wm) / denom));
+}
+
+// BSDF::sample_f, material/mod.rs:76-86
+RT_DEV bool bsdf_sample_f(const Material &m, V3 n, V3 wo, float u0, float u1, float u2, BxdfSample &o) {
+    Frame fr = frame_new(n);
+    V3 wo_local = to_local(fr, wo);
+    if (wo_local.z == 0.0f) return false;
+    bool ok;
+    if (m.kind == MAT_DIFFUSE)
+        ok = diffuse_sample_f(m, wo_local, u0, u1, o);
+    else if (m.kind == MAT_DIELECTRIC)
+        ok = dielectric_sample_f(m, wo_local, u0, u1, u2, o);
+    else if (m.kind == MAT_THIN)
+        ok = thin_dielectric_sample_f(m, wo_local, u2, o);
+    else
+        ok = false; // EmitBxDF::sample_f -> None, material/mod.rs:387-389
+    if (!ok) return false;
+    o.wi = from_local(fr, o.wi);
+    return true;
+}
+
+// BSDF::f, material/mod.rs:88-91
+RT_DEV V3 bsdf_f(const Material &m, V3 n, V3 wo, V3 wi) {
+    Frame fr = frame_new(n);
+    V3 wol = to_local(fr, wo);
+    V3 wil = to_local(fr, wi);
+    if (m.kind == MAT_DIFFUSE) {
+        if (!same_hemisphere(wol, wil)) return mk(0.0f, 0.0f, 0.0f);
+        return mk(RT_FRAC_1_PI * m.r, RT_FRAC_1_PI * m.g, RT_FRAC_1_PI * m.b);
+    }
+    if (m.kind == MAT_DIELECTRIC) return dielectric_f(m, wol, wil);
+    return mk(0.0f, 0.0f, 0.0f);
+}
+
+RT_DEV V3 material_le(const Material &m) {
+    if (m.kind == MAT_EMIT) return mk(m.r, m.g, m.b);
+    return mk(0.0f, 0.0f, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------- camera
+
+// glam Quat * Vec3
+RT_DEV V3 quat_mul_vec3(const float q[4], V3 v) {
+    float w = q[3];
+    V3 b = mk(q[0], q[1], q[2]);
+    float b2 = dot(b, b);
+    return add(add(scale(w * w - b2, v), scale(dot(v, b) * 2.0f, b)), scale(w * 2.0f, cross(b, v)));
+}
+
+// executor.rs:254-267 + sampler.rs:91-102 + filter.rs:23-32 + camera.rs:62-85.  strata = floor(sqrt(spp)).
+RT_DEV void camera_ray(const CameraView &cam, uint32_t strata, uint64_t seed, uint32_t x, uint32_t y, uint32_t sample,
+                       V3 &org, V3 &dir) {
+    uint32_t n = strata;
+    uint32_t index = sample % (n * n);
+    float cx = (float)(index % n), cy = (float)(index / n);
+    float r[4];
+    uniform4(seed, x, y, sample, 0u, r);
+    float px = (cx + r[0]) / (float)n, py = (cy + r[1]) / (float)n;
+    float offx = lerp_ext(px, -0.7f, 0.7f), offy = lerp_ext(py, -0.7f, 0.7f);
+    float cxp = ((float)x + 0.5f) + offx, cyp = ((float)y + 0.5f) + offy;
+    float vx = 2.0f * (cxp / (float)cam.width) - 1.0f;
+    float vy = 2.0f * (cyp / (float)cam.height) - 1.0f;
+    V3 lens = mk(cam.lens[0], cam.lens[1], cam.lens[2]);
+    V3 sensor = mk(lens.x + vx * cam.half_width, lens.y + vy * cam.half_height, lens.z + cam.focal_length);
+    float dx = (cx + r[2]) / (float)n, dy = (cy + r[3]) / (float)n;
+    float ha = cam.aperture / 2.0f;
+    V3 dst = mk(lens.x + ha * dx, lens.y + ha * dy, lens.z + ha * 0.0f);
+    org = lens;
+    dir = normalize(quat_mul_vec3(cam.rot, sub(dst, sensor)));
+}
+
+// ---------------------------------------------------------------------------------------------- closest hit
+
+struct Closest {
+    float t;
+    uint32_t gidx; // global primitive index of the best candidate, RT_EMPTY = none
+    uint32_t slot; // its slot in the primitive array
+    float u, v;
+    V3 ng; // spheres only
+};
+
+// Candidate order: smaller t wins, equal t goes to the smaller global primitive index, so the result is the same
+// for every traversal order.
+RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnear, Closest &best) {
+    const F4 *p = sv.prims + (size_t)slot * RT_PRIM_F4;
+    F4 a = p[0], b = p[1], c = p[2];
+    uint32_t gidx = __builtin_bit_cast(uint32_t, c.y);
+    uint32_t geom = __builtin_bit_cast(uint32_t, c.z);
+    float t, u = 0.0f, v = 0.0f;
+    V3 ng = mk(0.0f, 0.0f, 0.0f);
+    if (geom & RT_SPHERE) {
+        // Embree's sphere-point formulation: project the centre on the ray, compare the perpendicular distance
+        // with the radius; Ng = hit - centre = -+td * d - perp.
+        V3 centre = mk(a.x, a.y, a.z);
+        float radius = a.w;
+        float rd2 = 1.0f / dot(d, d);
+        V3 c0 = sub(centre, o);
+        float proj = dot(c0, d) * rd2;
+        V3 perp = sub(c0, scale(proj, d));
+        float l2 = dot(perp, perp);
+        float r2 = radius * radius;
+        if (!(l2 <= r2)) return;
+        float td = sqrtf((r2 - l2) * rd2);
+        float t_front = proj - td;
+        float t_back = proj + td;
+        if (tnear <= t_front && t_front <= best.t) {
+            t = t_front;
+            ng = sub(scale(-td, d), perp);
+        } else if (tnear <= t_back && t_back <= best.t) {
+            t = t_back;
+            ng = sub(scale(td, d), perp);
+        } else {
+            return;
+        }
+    } else {
+        // Moeller-Trumbore, no culling; edges inclusive; NaNs reject.
+        V3 v0 = mk(a.x, a.y, a.z);
+        V3 e1 = mk(a.w, b.x, b.y);
+        V3 e2 = mk(b.z, b.w, c.x);
+        V3 pv = cross(d, e2);
+        float det = dot(e1, pv);
+        if (!(det != 0.0f)) return;
+        float inv = 1.0f / det;
+        V3 tv = sub(o, v0);
+        u = dot(tv, pv) * inv;
+        if (!(u >= 0.0f && u <= 1.0f)) return;
+        V3 q = cross(tv, e1);
+        v = dot(d, q) * inv;
+        if (!(v >= 0.0f && u + v <= 1.0f)) return;
+        t = dot(e2, q) * inv;
+        if (!(t > tnear)) return;
+    }
+    if (t < best.t || (t == best.t && gidx < best.gidx)) {
+        best.t = t;
+        best.gidx = gidx;
+        best.slot = slot;
+        best.u = u;
+        best.v = v;
+        best.ng = ng;
+    }
+}
+
+// Reciprocal that never produces inf, so that 0 * inv is 0 and not NaN in the slab test.
+RT_DEV float safe_rcp(float d) { return 1.0f / (fabsf(d) > 1e-20f ? d : copysignf(1e-20f, d)); }
+
+// Closest hit of o + t d over (tnear, tfar] in the 4-wide BVH.  `Stack` offers push(uint32_t) / pop() / empty();
+// the tree's worst-case stack need is known at commit time and the kernels are instantiated with enough room.
+// Visit counters (may be null) count node and primitive fetches.
+template <class Stack>
+RT_DEV void closest_hit(const SceneView &sv, V3 o, V3 d, float tnear, float tfar, Stack &st, Closest &best,
+                        uint32_t *node_visits, uint32_t *prim_tests) {
+    best.t = tfar;
+    best.gidx = RT_EMPTY;
+    best.slot = 0;
+    best.u = best.v = 0.0f;
+    best.ng = mk(0.0f, 0.0f, 0.0f);
+    if (sv.n_nodes == 0) return;
+    const float ix = safe_rcp(d.x), iy = safe_rcp(d.y), iz = safe_rcp(d.z);
+    uint32_t cur = 0; // root
+    for (;;) {
+        if (!(cur & RT_LEAF)) {
+            const F4 *n = sv.nodes + (size_t)cur * RT_NODE_F4;
+            F4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5];
+            F4 cf = n[6];
+            if (node_visits) ++*node_visits;
+            const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, lys[4] = {ly.x, ly.y, ly.z, ly.w};
+            const float lzs[4] = {lz.x, lz.y, lz.z, lz.w}, hxs[4] = {hx.x, hx.y, hx.z, hx.w};
+            const float hys[4] = {hy.x, hy.y, hy.z, hy.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
+            const uint32_t ch[4] = {__builtin_bit_cast(uint32_t, cf.x), __builtin_bit_cast(uint32_t, cf.y),
+                                    __builtin_bit_cast(uint32_t, cf.z), __builtin_bit_cast(uint32_t, cf.w)};
+            float tn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t0x = (lxs[k] - o.x) * ix, t1x = (hxs[k] - o.x) * ix;
+                float t0y = (lys[k] - o.y) * iy, t1y = (hys[k] - o.y) * iy;
+                float t0z = (lzs[k] - o.z) * iz, t1z = (hzs[k] - o.z) * iz;
+                float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tnear));
+                float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
+                bool hit = (ch[k] != RT_EMPTY) && (tmin <= tmax * 1.0000004f);
+                tn[k] = hit ? tmin : INFINITY;
+            }
+            // 4-element sorting network on (entry distance, child), nearest first; misses carry +inf and RT_EMPTY
+            float a0 = tn[0], a1 = tn[1], a2 = tn[2], a3 = tn[3];
+            uint32_t i0 = a0 < INFINITY ? ch[0] : RT_EMPTY, i1 = a1 < INFINITY ? ch[1] : RT_EMPTY;
+            uint32_t i2 = a2 < INFINITY ? ch[2] : RT_EMPTY, i3 = a3 < INFINITY ? ch[3] : RT_EMPTY;
+#define RT_CSWAP(ta, ia, tb, ib)          \
+    {                                     \
+        bool sw = tb < ta;                \
+        float tlo = sw ? tb : ta;         \
+        float thi = sw ? ta : tb;         \
+        uint32_t ilo = sw ? ib : ia;      \
+        uint32_t ihi = sw ? ia : ib;      \
+        ta = tlo;                         \
+        tb = thi;                         \
+        ia = ilo;                         \
+        ib = ihi;                         \
+    }
+            RT_CSWAP(a0, i0, a1, i1)
+            RT_CSWAP(a2, i2, a3, i3)
+            RT_CSWAP(a0, i0, a2, i2)
+            RT_CSWAP(a1, i1, a3, i3)
+            RT_CSWAP(a1, i1, a2, i2)
+#undef RT_CSWAP
+            if (i0 == RT_EMPTY) {
+                if (st.empty()) break;
+                cur = st.pop();
+                continue;
+            }
+            if (i3 != RT_EMPTY) st.push(i3);
+            if (i2 != RT_EMPTY) st.push(i2);
+            if (i1 != RT_EMPTY) st.push(i1);
+            cur = i0;
+        } else {
+            uint32_t first = cur & 0x0FFFFFFFu;
+            uint32_t count = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                if (prim_tests) ++*prim_tests;
+                test_prim(sv, first + k, o, d, tnear, best);
+            }
+            if (st.empty()) break;
+            cur = st.pop();
+        }
+    }
+}
+
+struct HitInfo {
+    bool hit;
+    float t;
+    V3 pos;
+    V3 n;
+    float u, v;
+    uint32_t geom_id, prim_id, mat_id;
+};
+
+// embree.rs:115-137: position recomputed as org + t * dir, normal = normalize_or_zero(Ng), material by geometry.
+RT_DEV void finish_hit(const SceneView &sv, V3 o, V3 d, const Closest &best, HitInfo &h) {
+    if (best.gidx == RT_EMPTY) {
+        h.hit = false;
+        h.t = INFINITY;
+        h.pos = mk(0.0f, 0.0f, 0.0f);
+        h.n = mk(0.0f, 0.0f, 0.0f);
+        h.u = h.v = 0.0f;
+        h.geom_id = h.prim_id = RT_EMPTY;
+        h.mat_id = 0;
+        return;
+    }
+    const F4 *p = sv.prims + (size_t)best.slot * RT_PRIM_F4;
+    F4 a = p[0], b = p[1], c = p[2];
+    uint32_t geom = __builtin_bit_cast(uint32_t, c.z);
+    V3 ng = best.ng;
+    if (!(geom & RT_SPHERE)) ng = cross(mk(a.w, b.x, b.y), mk(b.z, b.w, c.x));
+    h.hit = true;
+    h.t = best.t;
+    h.pos = mk(o.x + best.t * d.x, o.y + best.t * d.y, o.z + best.t * d.z);
+    h.n = normalize_or_zero(ng);
+    h.u = best.u;
+    h.v = best.v;
+    h.geom_id = geom & ~RT_SPHERE;
+    h.prim_id = __builtin_bit_cast(uint32_t, c.w);
+    h.mat_id = h.geom_id < sv.n_geoms ? sv.geom_material[h.geom_id] : 0u;
+    if (h.mat_id >= sv.n_materials) h.mat_id = 0u;
+}
+
+// ---------------------------------------------------------------------------------------------- shading step
+
+// One vertex of the front-to-back path estimator.  On entry beta is the throughput carried to this vertex.
+// Returns true when the path continues (org/dir/beta updated); otherwise `radiance` holds the path's final colour.
+// first-hit outputs (normal, position, albedo, z) are meaningful when depth == 0.
+struct VertexOut {
+    V3 normal, position, albedo;
+    float z;
+    float t_add; // distance to add to the path's ray_depth
+    V3 radiance;
+};
+
+RT_DEV bool shade_vertex(const SceneView &sv, const HitInfo &h, uint32_t integrator, uint64_t seed, uint32_t x, uint32_t y,
+                         uint32_t sample, uint32_t depth, V3 &org, V3 &dir, V3 &beta, VertexOut &out) {
+    out.normal = mk(0.0f, 0.0f, 0.0f);
+    out.position = mk(0.0f, 0.0f, 0.0f);
+    out.albedo = mk(0.0f, 0.0f, 0.0f);
+    out.z = 0.0f;
+    out.t_add = 0.0f;
+    if (!h.hit) {
+        out.radiance = mul(beta, mk(0.5f, 0.3f, 1.0f)); // integrators/mod.rs:19
+        return false;
+    }
+    const Material m = sv.materials[h.mat_id];
+    float u[4];
+    uniform4(seed, x, y, sample, 1u + depth, u);
+    V3 wo = neg(dir);
+    V3 wi, f, weight_scale_fcos;
+    if (integrator == 0u) {
+        BxdfSample sm;
+        if (!bsdf_sample_f(m, h.n, wo, u[0], u[1], u[2], sm)) {
+            sm.wi = mk(0.0f, 0.0f, 0.0f);
+            sm.f = mk(0.0f, 0.0f, 0.0f);
+            sm.pdf = 1.0f;
+        }
+        wi = sm.wi;
+        f = sm.f;
+        V3 fcos = scale(fabsf(dot(h.n, wi)), f);
+        out.normal = h.n;
+        out.position = h.pos;
+        out.albedo = f;
+        out.z = h.t;
+        out.t_add = h.t;
+        if (!(fabsf(max_element(fcos)) != 0.0f)) {
+            out.radiance = mul(beta, material_le(m));
+            return false;
+        }
+        weight_scale_fcos = scale(1.0f / sm.pdf, fcos); // pathtracing.rs:60
+    } else {
+        wi = uniform_unit_sphere3(u[0], u[1]);
+        f = bsdf_f(m, h.n, wo, wi);
+        V3 fcos = scale(fabsf(dot(h.n, wi)), f);
+        out.normal = h.n;
+        out.position = h.pos;
+        out.albedo = f;
+        out.z = h.t;
+        out.t_add = (depth == 0u) ? h.t : 0.0f; // randomwalk.rs:65: ray_depth is the first hit's t only
+        if (!(fabsf(max_element(fcos)) != 0.0f)) {
+            out.radiance = mul(beta, material_le(m));
+            return false;
+        }
+        weight_scale_fcos = scale(RT_FRAC_1_PI / 4.0f, fcos); // randomwalk.rs:54
+    }
+    beta = mul(beta, weight_scale_fcos);
+    org = h.pos;
+    dir = wi;
+    return true;
+}
+
+} // namespace rtd

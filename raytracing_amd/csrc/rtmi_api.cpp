@@ -1,0 +1,660 @@
+// rtmi_api.cpp -- the C ABI of include/rtmi.h: scene assembly, OBJ loading, commit (BVH build + upload), batch
+// intersection and the wavefront render driver.  Host side only; the kernels are in kernels.hip.
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rtmi.h"
+#include "bvh.h"
+#include "kernels.h"
+#include "obj_loader.h"
+#include "scene_build.h"
+
+using rts::HostPrim;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+} // namespace
+
+struct rtmi_device {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    std::mutex lock;
+    bool count_visits = false;
+    uint32_t *d_visits = nullptr; // two 64-bit counters
+    int n_cu = 256;
+};
+
+struct rtmi_scene {
+    rtmi_device *dev = nullptr;
+    std::vector<rtd::Material> materials;
+    std::vector<float> lights;
+    std::vector<HostPrim> prims;
+    std::vector<uint32_t> geom_material;
+    bool committed = false;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    rtmi_scene_info info{};
+    rtd::F4 *d_nodes = nullptr;
+    rtd::F4 *d_prims = nullptr;
+    uint32_t *d_geom_material = nullptr;
+    rtd::Material *d_materials = nullptr;
+    rtd::SceneView view{};
+};
+
+struct rtmi_film {
+    rtmi_device *dev = nullptr;
+    size_t n_pixels = 0;
+    uint32_t *d_xy = nullptr;
+    float *d_accum = nullptr;
+    bool own_accum = false;
+    // workspace, grown on demand
+    size_t cap_paths = 0;
+    float *d_state = nullptr;
+    uint32_t *d_queue[2] = {nullptr, nullptr};
+    size_t cap_counters = 0;
+    uint32_t *d_counts = nullptr; // counts + work, cap_counters entries each
+    float *d_resolve = nullptr;
+};
+
+namespace {
+
+int use_device(rtmi_device *dev) {
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    return RTMI_OK;
+}
+
+void free_scene_device(rtmi_scene *s) {
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_prims) (void)hipFree(s->d_prims);
+    if (s->d_geom_material) (void)hipFree(s->d_geom_material);
+    if (s->d_materials) (void)hipFree(s->d_materials);
+    s->d_nodes = s->d_prims = nullptr;
+    s->d_geom_material = nullptr;
+    s->d_materials = nullptr;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rtmi_last_error(void) { return g_error.c_str(); }
+const char *rtmi_version(void) { return "rtmi 0.1 (gfx950)"; }
+
+int rtmi_device_create(int hip_ordinal, rtmi_device **out) {
+    if (!out) return fail(RTMI_ERR_ARG, "rtmi_device_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(RTMI_ERR_DEVICE, "no HIP device available");
+    int ordinal = hip_ordinal;
+    if (ordinal < 0) HIP_TRY(hipGetDevice(&ordinal));
+    if (ordinal >= count) return fail(RTMI_ERR_ARG, "HIP device ordinal out of range");
+    HIP_TRY(hipSetDevice(ordinal));
+    rtmi_device *d = new rtmi_device();
+    d->ordinal = ordinal;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+        d->n_cu = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete d;
+        return fail(RTMI_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    e = hipMalloc((void **)&d->d_visits, 16);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(d->stream);
+        delete d;
+        return fail(RTMI_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    (void)hipMemset(d->d_visits, 0, 16);
+    *out = d;
+    return RTMI_OK;
+}
+
+void rtmi_device_destroy(rtmi_device *dev) {
+    if (!dev) return;
+    (void)hipSetDevice(dev->ordinal);
+    if (dev->stream) {
+        (void)hipStreamSynchronize(dev->stream);
+        (void)hipStreamDestroy(dev->stream);
+    }
+    if (dev->d_visits) (void)hipFree(dev->d_visits);
+    delete dev;
+}
+
+int rtmi_device_count_visits(rtmi_device *dev, int enable) {
+    if (!dev) return fail(RTMI_ERR_ARG, "device is NULL");
+    std::lock_guard<std::mutex> g(dev->lock);
+    if (int rc = use_device(dev)) return rc;
+    dev->count_visits = enable != 0;
+    HIP_TRY(hipMemsetAsync(dev->d_visits, 0, 16, dev->stream));
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    return RTMI_OK;
+}
+
+int rtmi_device_get_visits(rtmi_device *dev, uint64_t out[2]) {
+    if (!dev || !out) return fail(RTMI_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> g(dev->lock);
+    if (int rc = use_device(dev)) return rc;
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    HIP_TRY(hipMemcpy(out, dev->d_visits, 16, hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+void *rtmi_device_stream(rtmi_device *dev) { return dev ? (void *)dev->stream : nullptr; }
+
+int rtmi_scene_create(rtmi_device *dev, rtmi_scene **out) {
+    if (!dev || !out) return fail(RTMI_ERR_ARG, "rtmi_scene_create: NULL argument");
+    rtmi_scene *s = new rtmi_scene();
+    s->dev = dev;
+    rtd::Material sky{}; // embree.rs:41-46
+    sky.kind = rtd::MAT_DIFFUSE;
+    s->materials.push_back(sky);
+    *out = s;
+    return RTMI_OK;
+}
+
+void rtmi_scene_destroy(rtmi_scene *scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->dev->ordinal);
+    (void)hipStreamSynchronize(scene->dev->stream);
+    free_scene_device(scene);
+    delete scene;
+}
+
+int rtmi_scene_insert_material(rtmi_scene *scene, const rtmi_material *mat, uint32_t *out_id) {
+    if (!scene || !mat) return fail(RTMI_ERR_ARG, "rtmi_scene_insert_material: NULL argument");
+    if (scene->committed) return fail(RTMI_ERR_STATE, "scene already committed");
+    if (mat->kind > RTMI_MAT_EMIT) return fail(RTMI_ERR_ARG, "unknown material kind");
+    rtd::Material m{};
+    m.kind = mat->kind;
+    m.r = mat->rgb[0];
+    m.g = mat->rgb[1];
+    m.b = mat->rgb[2];
+    m.ior = mat->ior;
+    m.roughness = mat->roughness;
+    if (out_id) *out_id = (uint32_t)scene->materials.size();
+    scene->materials.push_back(m);
+    return RTMI_OK;
+}
+
+int rtmi_scene_insert_light(rtmi_scene *scene, const float pos[3]) {
+    if (!scene || !pos) return fail(RTMI_ERR_ARG, "rtmi_scene_insert_light: NULL argument");
+    if (scene->committed) return fail(RTMI_ERR_STATE, "scene already committed");
+    scene->lights.insert(scene->lights.end(), pos, pos + 3);
+    return RTMI_OK;
+}
+
+int rtmi_scene_insert_mesh(rtmi_scene *scene, uint32_t material, const float *vertices, size_t n_vertices,
+                           const uint32_t *indices, size_t n_triangles, uint32_t *out_geom) {
+    if (!scene || (n_vertices && !vertices) || (n_triangles && !indices))
+        return fail(RTMI_ERR_ARG, "rtmi_scene_insert_mesh: NULL argument");
+    if (scene->committed) return fail(RTMI_ERR_STATE, "scene already committed");
+    if (material >= scene->materials.size()) return fail(RTMI_ERR_ARG, "unknown material id");
+    if (scene->prims.size() + n_triangles >= (1u << 28)) return fail(RTMI_ERR_LIMIT, "more than 2^28 primitives");
+    for (size_t i = 0; i < 3 * n_triangles; ++i)
+        if (indices[i] >= n_vertices) return fail(RTMI_ERR_ARG, "vertex index out of range");
+    const uint32_t geom = (uint32_t)scene->geom_material.size();
+    scene->geom_material.push_back(material);
+    scene->prims.reserve(scene->prims.size() + n_triangles);
+    for (size_t i = 0; i < n_triangles; ++i) {
+        HostPrim p{};
+        memcpy(p.a, vertices + 3 * (size_t)indices[3 * i], 12);
+        memcpy(p.b, vertices + 3 * (size_t)indices[3 * i + 1], 12);
+        memcpy(p.c, vertices + 3 * (size_t)indices[3 * i + 2], 12);
+        p.geom = geom;
+        p.prim = (uint32_t)i;
+        p.is_sphere = 0;
+        scene->prims.push_back(p);
+    }
+    if (out_geom) *out_geom = geom;
+    return RTMI_OK;
+}
+
+int rtmi_scene_insert_sphere(rtmi_scene *scene, uint32_t material, const float center[3], float radius,
+                             uint32_t *out_geom) {
+    if (!scene || !center) return fail(RTMI_ERR_ARG, "rtmi_scene_insert_sphere: NULL argument");
+    if (scene->committed) return fail(RTMI_ERR_STATE, "scene already committed");
+    if (material >= scene->materials.size()) return fail(RTMI_ERR_ARG, "unknown material id");
+    if (scene->prims.size() + 1 >= (1u << 28)) return fail(RTMI_ERR_LIMIT, "more than 2^28 primitives");
+    const uint32_t geom = (uint32_t)scene->geom_material.size();
+    scene->geom_material.push_back(material);
+    HostPrim p{};
+    memcpy(p.a, center, 12);
+    p.b[0] = radius;
+    p.geom = geom;
+    p.prim = 0;
+    p.is_sphere = 1;
+    scene->prims.push_back(p);
+    if (out_geom) *out_geom = geom;
+    return RTMI_OK;
+}
+
+int rtmi_scene_load_obj(rtmi_scene *scene, const char *path, const rtmi_transform *transform,
+                        uint32_t default_material, uint32_t *out_first_geom, uint32_t *out_n_geoms) {
+    if (!scene || !path || !transform) return fail(RTMI_ERR_ARG, "rtmi_scene_load_obj: NULL argument");
+    if (scene->committed) return fail(RTMI_ERR_STATE, "scene already committed");
+    if (default_material >= scene->materials.size()) return fail(RTMI_ERR_ARG, "unknown default material id");
+    rto::ObjFile obj;
+    std::string err;
+    if (!rto::load_obj(path, obj, err)) return fail(RTMI_ERR_IO, err);
+    // loader/obj.rs:36-91: one Diffuse(Kd) per MTL material, in file order
+    std::vector<uint32_t> ids;
+    if (obj.materials_ok) {
+        for (const auto &m : obj.materials) {
+            rtmi_material d{};
+            d.kind = RTMI_MAT_DIFFUSE;
+            memcpy(d.rgb, m.diffuse, 12);
+            uint32_t id = 0;
+            if (int rc = rtmi_scene_insert_material(scene, &d, &id)) return rc;
+            ids.push_back(id);
+        }
+    }
+    const uint32_t first = (uint32_t)scene->geom_material.size();
+    for (auto &model : obj.models) {
+        uint32_t mat = default_material; // loader/obj.rs:100-107
+        if (obj.materials_ok && model.material_id >= 0 && (size_t)model.material_id < ids.size())
+            mat = ids[(size_t)model.material_id];
+        for (size_t v = 0; v + 2 < model.positions.size(); v += 3) rts::apply_transform(transform->translation, transform->scale, transform->rot, &model.positions[v]);
+        if (int rc = rtmi_scene_insert_mesh(scene, mat, model.positions.data(), model.positions.size() / 3,
+                                            model.indices.data(), model.indices.size() / 3, nullptr))
+            return rc;
+    }
+    if (out_first_geom) *out_first_geom = first;
+    if (out_n_geoms) *out_n_geoms = (uint32_t)scene->geom_material.size() - first;
+    return RTMI_OK;
+}
+
+int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) {
+    if (!scene) return fail(RTMI_ERR_ARG, "rtmi_scene_commit: scene is NULL");
+    if (scene->committed) return fail(RTMI_ERR_STATE, "scene already committed");
+    rtmi_device *dev = scene->dev;
+    std::lock_guard<std::mutex> g(dev->lock);
+    if (int rc = use_device(dev)) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t n = scene->prims.size();
+    rtb::WideBvh bvh;
+    std::vector<rtd::F4> prims;
+    std::function<bool(double)> cb;
+    if (progress) cb = [progress, user](double a) { return progress(a, user) != 0; };
+    if (!rts::build_scene(scene->prims, bvh, prims, scene->lo, scene->hi, cb))
+        return fail(RTMI_ERR_CANCELLED, "commit cancelled by the progress callback");
+    if (bvh.stack_need > rtk::MAX_STACK)
+        return fail(RTMI_ERR_LIMIT, "BVH needs a deeper traversal stack than the kernels provide");
+    free_scene_device(scene);
+    const size_t node_bytes = bvh.nodes.size() * sizeof(rtd::F4);
+    const size_t prim_bytes = prims.size() * sizeof(rtd::F4);
+    if (node_bytes) {
+        HIP_TRY(hipMalloc((void **)&scene->d_nodes, node_bytes));
+        HIP_TRY(hipMemcpy(scene->d_nodes, bvh.nodes.data(), node_bytes, hipMemcpyHostToDevice));
+    }
+    if (prim_bytes) {
+        HIP_TRY(hipMalloc((void **)&scene->d_prims, prim_bytes));
+        HIP_TRY(hipMemcpy(scene->d_prims, prims.data(), prim_bytes, hipMemcpyHostToDevice));
+    }
+    const size_t gm_bytes = std::max<size_t>(1, scene->geom_material.size()) * sizeof(uint32_t);
+    HIP_TRY(hipMalloc((void **)&scene->d_geom_material, gm_bytes));
+    if (!scene->geom_material.empty())
+        HIP_TRY(hipMemcpy(scene->d_geom_material, scene->geom_material.data(),
+                          scene->geom_material.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&scene->d_materials, scene->materials.size() * sizeof(rtd::Material)));
+    HIP_TRY(hipMemcpy(scene->d_materials, scene->materials.data(), scene->materials.size() * sizeof(rtd::Material),
+                      hipMemcpyHostToDevice));
+    scene->view.nodes = scene->d_nodes;
+    scene->view.prims = scene->d_prims;
+    scene->view.geom_material = scene->d_geom_material;
+    scene->view.materials = scene->d_materials;
+    scene->view.n_nodes = bvh.n_nodes;
+    scene->view.n_prims = (uint32_t)n;
+    scene->view.n_geoms = (uint32_t)scene->geom_material.size();
+    scene->view.n_materials = (uint32_t)scene->materials.size();
+    scene->info.n_prims = n;
+    scene->info.n_nodes = bvh.n_nodes;
+    scene->info.node_bytes = node_bytes;
+    scene->info.prim_bytes = prim_bytes;
+    scene->info.n_geoms = scene->view.n_geoms;
+    scene->info.n_materials = scene->view.n_materials;
+    scene->info.stack_need = bvh.stack_need;
+    scene->info.max_depth = bvh.depth;
+    scene->info.sah_cost = bvh.sah_cost;
+    scene->info.build_ms =
+        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    scene->committed = true;
+    if (progress) progress(1.0, user);
+    return RTMI_OK;
+}
+
+int rtmi_scene_bounds(const rtmi_scene *scene, float lo[3], float hi[3]) {
+    if (!scene || !lo || !hi) return fail(RTMI_ERR_ARG, "rtmi_scene_bounds: NULL argument");
+    if (!scene->committed) return fail(RTMI_ERR_STATE, "scene not committed");
+    memcpy(lo, scene->lo, 12);
+    memcpy(hi, scene->hi, 12);
+    return RTMI_OK;
+}
+
+int rtmi_scene_get_info(const rtmi_scene *scene, rtmi_scene_info *out) {
+    if (!scene || !out) return fail(RTMI_ERR_ARG, "rtmi_scene_get_info: NULL argument");
+    if (!scene->committed) return fail(RTMI_ERR_STATE, "scene not committed");
+    *out = scene->info;
+    return RTMI_OK;
+}
+
+int rtmi_scene_geometry_material(const rtmi_scene *scene, uint32_t geom, uint32_t *out_material) {
+    if (!scene || !out_material) return fail(RTMI_ERR_ARG, "rtmi_scene_geometry_material: NULL argument");
+    if (geom >= scene->geom_material.size()) return fail(RTMI_ERR_ARG, "unknown geometry id");
+    *out_material = scene->geom_material[geom];
+    return RTMI_OK;
+}
+
+static uint32_t stack_for(const rtmi_scene *scene) {
+    const uint32_t need = scene->info.stack_need;
+    return need <= 32 ? 32u : (need <= 64 ? 64u : 128u);
+}
+
+int rtmi_intersect_device(rtmi_scene *scene, const rtmi_ray *d_rays, rtmi_hit *d_hits, size_t n, void *hip_stream) {
+    if (!scene || (n && (!d_rays || !d_hits))) return fail(RTMI_ERR_ARG, "rtmi_intersect_device: NULL argument");
+    if (!scene->committed) return fail(RTMI_ERR_STATE, "scene not committed");
+    if (int rc = use_device(scene->dev)) return rc;
+    static_assert(sizeof(rtmi_ray) == sizeof(rtk::RayAoS) && sizeof(rtmi_hit) == sizeof(rtk::HitAoS), "layout");
+    if (rtk::launch_intersect(scene->view, reinterpret_cast<const rtk::RayAoS *>(d_rays),
+                              reinterpret_cast<rtk::HitAoS *>(d_hits), n, stack_for(scene), hip_stream))
+        return fail(RTMI_ERR_DEVICE, "intersect kernel launch failed");
+    return RTMI_OK;
+}
+
+int rtmi_intersect(rtmi_scene *scene, const rtmi_ray *rays, rtmi_hit *hits, size_t n) {
+    if (!scene || (n && (!rays || !hits))) return fail(RTMI_ERR_ARG, "rtmi_intersect: NULL argument");
+    if (!scene->committed) return fail(RTMI_ERR_STATE, "scene not committed");
+    if (n == 0) return RTMI_OK;
+    rtmi_device *dev = scene->dev;
+    std::lock_guard<std::mutex> g(dev->lock);
+    if (int rc = use_device(dev)) return rc;
+    rtmi_ray *d_rays = nullptr;
+    rtmi_hit *d_hits = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rays, n * sizeof(rtmi_ray)));
+    hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(rtmi_hit));
+    if (e != hipSuccess) {
+        (void)hipFree(d_rays);
+        return fail(RTMI_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    int rc = RTMI_OK;
+    e = hipMemcpyAsync(d_rays, rays, n * sizeof(rtmi_ray), hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) {
+        rc = rtmi_intersect_device(scene, d_rays, d_hits, n, dev->stream);
+        if (rc == RTMI_OK) e = hipMemcpyAsync(hits, d_hits, n * sizeof(rtmi_hit), hipMemcpyDeviceToHost, dev->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(dev->stream);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    if (rc != RTMI_OK) return rc;
+    if (e != hipSuccess) return fail(RTMI_ERR_DEVICE, std::string("copy: ") + hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(RTMI_ERR_DEVICE, std::string("intersect: ") + hipGetErrorString(e2));
+    return RTMI_OK;
+}
+
+int rtmi_film_create(rtmi_device *dev, const uint32_t *xy, size_t n_pixels, float *d_accum, rtmi_film **out) {
+    if (!dev || !out || (n_pixels && !xy)) return fail(RTMI_ERR_ARG, "rtmi_film_create: NULL argument");
+    if (n_pixels >= (1ull << 31)) return fail(RTMI_ERR_LIMIT, "too many pixels in one film");
+    std::lock_guard<std::mutex> g(dev->lock);
+    if (int rc = use_device(dev)) return rc;
+    rtmi_film *f = new rtmi_film();
+    f->dev = dev;
+    f->n_pixels = n_pixels;
+    const size_t xy_bytes = std::max<size_t>(1, n_pixels) * 2 * sizeof(uint32_t);
+    hipError_t e = hipMalloc((void **)&f->d_xy, xy_bytes);
+    if (e == hipSuccess && n_pixels) e = hipMemcpy(f->d_xy, xy, n_pixels * 2 * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (d_accum) {
+            f->d_accum = d_accum;
+        } else {
+            const size_t bytes = std::max<size_t>(1, n_pixels) * RTMI_ACCUM_PLANES * sizeof(float);
+            e = hipMalloc((void **)&f->d_accum, bytes);
+            if (e == hipSuccess) {
+                f->own_accum = true;
+                e = hipMemset(f->d_accum, 0, bytes);
+            }
+        }
+    }
+    if (e != hipSuccess) {
+        if (f->d_xy) (void)hipFree(f->d_xy);
+        if (f->own_accum && f->d_accum) (void)hipFree(f->d_accum);
+        delete f;
+        return fail(RTMI_ERR_DEVICE, std::string("film allocation: ") + hipGetErrorString(e));
+    }
+    *out = f;
+    return RTMI_OK;
+}
+
+void rtmi_film_destroy(rtmi_film *film) {
+    if (!film) return;
+    (void)hipSetDevice(film->dev->ordinal);
+    (void)hipStreamSynchronize(film->dev->stream);
+    if (film->d_xy) (void)hipFree(film->d_xy);
+    if (film->own_accum && film->d_accum) (void)hipFree(film->d_accum);
+    if (film->d_state) (void)hipFree(film->d_state);
+    if (film->d_queue[0]) (void)hipFree(film->d_queue[0]);
+    if (film->d_queue[1]) (void)hipFree(film->d_queue[1]);
+    if (film->d_counts) (void)hipFree(film->d_counts);
+    if (film->d_resolve) (void)hipFree(film->d_resolve);
+    delete film;
+}
+
+int rtmi_film_clear(rtmi_film *film) {
+    if (!film) return fail(RTMI_ERR_ARG, "film is NULL");
+    std::lock_guard<std::mutex> g(film->dev->lock);
+    if (int rc = use_device(film->dev)) return rc;
+    HIP_TRY(hipMemsetAsync(film->d_accum, 0, film->n_pixels * RTMI_ACCUM_PLANES * sizeof(float), film->dev->stream));
+    HIP_TRY(hipStreamSynchronize(film->dev->stream));
+    return RTMI_OK;
+}
+
+float *rtmi_film_accum_device(rtmi_film *film) { return film ? film->d_accum : nullptr; }
+
+int rtmi_film_download(rtmi_film *film, float *accum) {
+    if (!film || !accum) return fail(RTMI_ERR_ARG, "rtmi_film_download: NULL argument");
+    std::lock_guard<std::mutex> g(film->dev->lock);
+    if (int rc = use_device(film->dev)) return rc;
+    HIP_TRY(hipStreamSynchronize(film->dev->stream));
+    HIP_TRY(hipMemcpy(accum, film->d_accum, film->n_pixels * RTMI_ACCUM_PLANES * sizeof(float),
+                      hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+int rtmi_film_resolve(rtmi_film *film, float *out, int srgb) {
+    if (!film || !out) return fail(RTMI_ERR_ARG, "rtmi_film_resolve: NULL argument");
+    if (film->n_pixels == 0) return RTMI_OK;
+    rtmi_device *dev = film->dev;
+    std::lock_guard<std::mutex> g(dev->lock);
+    if (int rc = use_device(dev)) return rc;
+    const size_t bytes = film->n_pixels * RTMI_RESOLVE_PLANES * sizeof(float);
+    if (!film->d_resolve) HIP_TRY(hipMalloc((void **)&film->d_resolve, bytes));
+    if (rtk::launch_resolve(film->d_accum, (uint32_t)film->n_pixels, film->d_resolve, srgb, dev->stream))
+        return fail(RTMI_ERR_DEVICE, "resolve kernel launch failed");
+    HIP_TRY(hipMemcpyAsync(out, film->d_resolve, bytes, hipMemcpyDeviceToHost, dev->stream));
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    return RTMI_OK;
+}
+
+int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, const rtmi_render_params *params,
+                rtmi_render_stats *stats) {
+    if (!scene || !film || !camera || !params) return fail(RTMI_ERR_ARG, "rtmi_render: NULL argument");
+    if (!scene->committed) return fail(RTMI_ERR_STATE, "scene not committed");
+    if (scene->dev != film->dev) return fail(RTMI_ERR_ARG, "scene and film belong to different devices");
+    if (params->sample_end < params->sample_begin) return fail(RTMI_ERR_ARG, "sample range is reversed");
+    if (params->spp == 0) return fail(RTMI_ERR_ARG, "spp must be at least 1");
+    if (params->integrator > RTMI_INTEGRATOR_RANDOM_WALK) return fail(RTMI_ERR_ARG, "unknown integrator");
+    if (camera->width == 0 || camera->height == 0) return fail(RTMI_ERR_ARG, "camera has no pixels");
+    if (stats) memset(stats, 0, sizeof *stats);
+    const uint32_t n_samples = params->sample_end - params->sample_begin;
+    const size_t npix = film->n_pixels;
+    if (n_samples == 0 || npix == 0 || params->max_depth == 0) return RTMI_OK; // nothing accumulates
+    if (params->max_depth > (1u << 20)) return fail(RTMI_ERR_LIMIT, "max_depth too large");
+
+    rtmi_device *dev = scene->dev;
+    std::lock_guard<std::mutex> g(dev->lock);
+    if (int rc = use_device(dev)) return rc;
+    hipStream_t stream = dev->stream;
+
+    // samples traced together per pass
+    const size_t target_paths = (size_t)8 << 20;
+    uint32_t spp_pass = params->samples_per_pass;
+    if (spp_pass == 0) spp_pass = (uint32_t)std::max<size_t>(1, target_paths / npix);
+    spp_pass = std::min(spp_pass, n_samples);
+    if ((size_t)spp_pass * npix >= (1ull << 31)) spp_pass = (uint32_t)std::max<size_t>(1, ((1ull << 31) - 1) / npix);
+    const size_t max_paths = (size_t)spp_pass * npix;
+    const uint32_t n_passes = (n_samples + spp_pass - 1) / spp_pass;
+    const size_t per_pass = (size_t)params->max_depth + 2;
+    const size_t n_counters = per_pass * n_passes;
+
+    if (film->cap_paths < max_paths) {
+        if (film->d_state) (void)hipFree(film->d_state);
+        if (film->d_queue[0]) (void)hipFree(film->d_queue[0]);
+        if (film->d_queue[1]) (void)hipFree(film->d_queue[1]);
+        film->d_state = nullptr;
+        film->d_queue[0] = film->d_queue[1] = nullptr;
+        film->cap_paths = 0;
+        HIP_TRY(hipMalloc((void **)&film->d_state, max_paths * rtk::STATE_PLANES * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&film->d_queue[0], max_paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&film->d_queue[1], max_paths * sizeof(uint32_t)));
+        film->cap_paths = max_paths;
+    }
+    if (film->cap_counters < n_counters) {
+        if (film->d_counts) (void)hipFree(film->d_counts);
+        film->d_counts = nullptr;
+        film->cap_counters = 0;
+        HIP_TRY(hipMalloc((void **)&film->d_counts, 2 * n_counters * sizeof(uint32_t)));
+        film->cap_counters = n_counters;
+    }
+    uint32_t *d_counts = film->d_counts;
+    uint32_t *d_work = film->d_counts + film->cap_counters;
+    HIP_TRY(hipMemsetAsync(film->d_counts, 0, 2 * film->cap_counters * sizeof(uint32_t), stream));
+
+    rtk::RenderArgs a{};
+    a.scene = scene->view;
+    a.camera.width = camera->width;
+    a.camera.height = camera->height;
+    a.camera.half_width = camera->half_width;
+    a.camera.half_height = camera->half_height;
+    a.camera.focal_length = camera->focal_length;
+    a.camera.aperture = camera->aperture;
+    memcpy(a.camera.lens, camera->lens, 12);
+    memcpy(a.camera.rot, camera->rot, 16);
+    a.pixels = film->d_xy;
+    a.state = film->d_state;
+    a.queue[0] = film->d_queue[0];
+    a.queue[1] = film->d_queue[1];
+    a.visit_counters = dev->count_visits ? dev->d_visits : nullptr;
+    a.n_pixels = (uint32_t)npix;
+    a.strata = (uint32_t)floorf(sqrtf((float)params->spp)); // executor.rs:218
+    if (a.strata == 0) a.strata = 1;
+    a.max_depth = params->max_depth;
+    a.integrator = params->integrator;
+    a.seed = params->seed;
+
+    const uint32_t stack = stack_for(scene);
+    // resident grid: LDS bounds the blocks per CU (stack * BLOCK * 4 bytes each of 160 KiB)
+    const uint32_t lds_per_block = stack * rtk::BLOCK * 4u;
+    uint32_t blocks_per_cu = std::min<uint32_t>(8u, (160u * 1024u) / lds_per_block);
+    if (blocks_per_cu == 0) blocks_per_cu = 1;
+    const uint32_t full_grid = (uint32_t)dev->n_cu * blocks_per_cu;
+
+    hipEvent_t ev_begin, ev_end;
+    HIP_TRY(hipEventCreate(&ev_begin));
+    HIP_TRY(hipEventCreate(&ev_end));
+    std::vector<hipEvent_t> ev_pass(2 * (size_t)n_passes);
+    for (auto &e : ev_pass) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(ev_begin, stream));
+    int rc = RTMI_OK;
+    uint32_t sample = params->sample_begin;
+    for (uint32_t pass = 0; pass < n_passes && rc == RTMI_OK; ++pass) {
+        const uint32_t k = std::min(spp_pass, params->sample_end - sample);
+        a.n_paths = (uint32_t)((size_t)k * npix);
+        a.sample_base = sample;
+        a.counts = d_counts + (size_t)pass * per_pass;
+        a.work = d_work + (size_t)pass * per_pass;
+        const uint32_t grid = std::min<uint32_t>(full_grid, (a.n_paths + rtk::BLOCK - 1) / rtk::BLOCK);
+        (void)hipEventRecord(ev_pass[2 * pass], stream);
+        for (uint32_t depth = 0; depth < params->max_depth; ++depth) {
+            if (rtk::launch_bounce(a, depth, stack, grid, stream)) {
+                rc = fail(RTMI_ERR_DEVICE, "bounce kernel launch failed");
+                break;
+            }
+        }
+        (void)hipEventRecord(ev_pass[2 * pass + 1], stream);
+        if (rc == RTMI_OK && rtk::launch_accumulate(a, film->d_accum, k, 1.0f, stream))
+            rc = fail(RTMI_ERR_DEVICE, "accumulate kernel launch failed");
+        sample += k;
+    }
+    (void)hipEventRecord(ev_end, stream);
+    hipError_t e = hipStreamSynchronize(stream);
+    if (rc == RTMI_OK && e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+    if (rc == RTMI_OK && stats) {
+        std::vector<uint32_t> counts(n_counters);
+        e = hipMemcpy(counts.data(), d_counts, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("counter readback: ") + hipGetErrorString(e));
+        uint32_t s2 = params->sample_begin;
+        for (uint32_t pass = 0; pass < n_passes; ++pass) {
+            const uint32_t k = std::min(spp_pass, params->sample_end - s2);
+            s2 += k;
+            stats->paths += (uint64_t)k * npix;
+            stats->rays += (uint64_t)k * npix;
+            for (uint32_t d = 1; d < params->max_depth; ++d) {
+                const uint32_t c = counts[(size_t)pass * per_pass + d];
+                stats->rays += c;
+                if (c && d > stats->max_bounces) stats->max_bounces = d;
+            }
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev_pass[2 * pass], ev_pass[2 * pass + 1]) == hipSuccess)
+                stats->bounce_ms += ms;
+        }
+        stats->passes = n_passes;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->gpu_ms = ms;
+    }
+    (void)hipEventDestroy(ev_begin);
+    (void)hipEventDestroy(ev_end);
+    for (auto &ev : ev_pass) (void)hipEventDestroy(ev);
+    return rc;
+}
+
+static uint32_t div_ceil_u32(uint32_t x, uint32_t y) { return x / y + (x % y != 0 ? 1u : 0u); }
+
+uint32_t rtmi_tile_count(uint32_t width, uint32_t height, uint32_t grain) {
+    if (grain == 0) return 0;
+    return div_ceil_u32(width, grain) * div_ceil_u32(height, grain);
+}
+
+int rtmi_tile_get(uint32_t offset_x, uint32_t offset_y, uint32_t width, uint32_t height, uint32_t grain,
+                  uint32_t idx, uint32_t out[4]) {
+    if (!out || grain == 0) return fail(RTMI_ERR_ARG, "rtmi_tile_get: bad argument");
+    if (idx >= rtmi_tile_count(width, height, grain)) return fail(RTMI_ERR_ARG, "tile index out of range");
+    const uint32_t cols = div_ceil_u32(width, grain);
+    const uint32_t x = idx % cols, y = idx / cols;
+    out[0] = offset_x + x * grain;
+    out[1] = offset_x + std::min(width, (x + 1) * grain);
+    out[2] = offset_y + y * grain;
+    out[3] = offset_y + std::min(height, (y + 1) * grain);
+    return RTMI_OK;
+}
+
+} // extern "C"

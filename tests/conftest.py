@@ -1,0 +1,58 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def same_bits(a, b):
+    """Bitwise equality of two f32 arrays, any NaN matching any NaN."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+
+
+def full_frame_xy(width, height):
+    ys, xs = np.mgrid[0:height, 0:width]
+    return np.stack([xs.ravel(), ys.ravel()], 1).astype(np.uint32)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def scene_classes():
+    from raytracing_amd import scenes
+    return scenes.AVAILABLE_SCENES
+
+
+@pytest.fixture(scope="session")
+def device():
+    from raytracing_amd import api
+    d = api.Device(0)
+    yield d
+    d.close()

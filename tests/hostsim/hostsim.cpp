@@ -1,0 +1,303 @@
+// hostsim.cpp -- TEST HARNESS, not part of the product.  Compiles the per-ray device code (rt_device.h) and the
+// host-side scene assembly (OBJ loader, BVH builder, flatten) with g++ so that they can be checked against the CPU
+// oracle, and single-stepped under gdb, on a machine without a GPU.  The loops below stand in for the kernels' glue
+// (queueing, compaction, accumulation order); the GPU tests cover the real kernels.
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#define RT_DEV inline
+#include "../../raytracing_amd/csrc/bvh.h"
+#include "../../raytracing_amd/csrc/obj_loader.h"
+#include "../../raytracing_amd/csrc/rt_device.h"
+#include "../../raytracing_amd/csrc/scene_build.h"
+
+using namespace rtd;
+
+namespace {
+
+struct VecStack {
+    uint32_t data[256];
+    int sp = 0;
+    int high = 0;
+    void push(uint32_t v) {
+        data[sp++] = v;
+        if (sp > high) high = sp;
+    }
+    uint32_t pop() { return data[--sp]; }
+    bool empty() const { return sp == 0; }
+};
+
+struct Scene {
+    std::vector<Material> materials;
+    std::vector<rts::HostPrim> prims;
+    std::vector<uint32_t> geom_material;
+    rtb::WideBvh bvh;
+    std::vector<F4> records;
+    float lo[3], hi[3];
+    SceneView view{};
+    int stack_high = 0;
+};
+
+struct Ray {
+    float org[3], tnear, dir[3], tfar;
+};
+struct Hit {
+    float t, pos[3], n[3], uv[2];
+    uint32_t geom_id, prim_id, mat_id;
+};
+struct Params {
+    uint32_t spp, sample_begin, sample_end, max_depth, integrator, samples_per_pass;
+    uint64_t seed;
+};
+
+} // namespace
+
+extern "C" {
+
+void *hs_scene_new() {
+    Scene *s = new Scene();
+    Material sky{};
+    sky.kind = MAT_DIFFUSE;
+    s->materials.push_back(sky);
+    return s;
+}
+void hs_scene_free(void *p) { delete (Scene *)p; }
+
+uint32_t hs_insert_material(void *p, uint32_t kind, const float rgb[3], float ior, float roughness) {
+    Scene *s = (Scene *)p;
+    Material m{};
+    m.kind = kind;
+    m.r = rgb[0];
+    m.g = rgb[1];
+    m.b = rgb[2];
+    m.ior = ior;
+    m.roughness = roughness;
+    s->materials.push_back(m);
+    return (uint32_t)s->materials.size() - 1;
+}
+
+uint32_t hs_insert_mesh(void *p, uint32_t material, const float *v, size_t nv, const uint32_t *idx, size_t nt) {
+    Scene *s = (Scene *)p;
+    (void)nv;
+    uint32_t geom = (uint32_t)s->geom_material.size();
+    s->geom_material.push_back(material);
+    for (size_t i = 0; i < nt; ++i) {
+        rts::HostPrim hp{};
+        memcpy(hp.a, v + 3 * (size_t)idx[3 * i], 12);
+        memcpy(hp.b, v + 3 * (size_t)idx[3 * i + 1], 12);
+        memcpy(hp.c, v + 3 * (size_t)idx[3 * i + 2], 12);
+        hp.geom = geom;
+        hp.prim = (uint32_t)i;
+        s->prims.push_back(hp);
+    }
+    return geom;
+}
+
+uint32_t hs_insert_sphere(void *p, uint32_t material, const float c[3], float r) {
+    Scene *s = (Scene *)p;
+    uint32_t geom = (uint32_t)s->geom_material.size();
+    s->geom_material.push_back(material);
+    rts::HostPrim hp{};
+    memcpy(hp.a, c, 12);
+    hp.b[0] = r;
+    hp.geom = geom;
+    hp.is_sphere = 1;
+    s->prims.push_back(hp);
+    return geom;
+}
+
+// Same steps as rtmi_scene_load_obj.  Returns the number of meshes inserted, -1 on error.
+int hs_load_obj(void *p, const char *path, const float tr[3], const float sc[3], const float rot[4],
+                uint32_t default_material) {
+    Scene *s = (Scene *)p;
+    rto::ObjFile obj;
+    std::string err;
+    if (!rto::load_obj(path, obj, err)) return -1;
+    std::vector<uint32_t> ids;
+    if (obj.materials_ok)
+        for (auto &m : obj.materials) ids.push_back(hs_insert_material(p, MAT_DIFFUSE, m.diffuse, 0.0f, 0.0f));
+    for (auto &model : obj.models) {
+        uint32_t mat = default_material;
+        if (obj.materials_ok && model.material_id >= 0 && (size_t)model.material_id < ids.size())
+            mat = ids[(size_t)model.material_id];
+        for (size_t v = 0; v + 2 < model.positions.size(); v += 3) rts::apply_transform(tr, sc, rot, &model.positions[v]);
+        hs_insert_mesh(p, mat, model.positions.data(), model.positions.size() / 3, model.indices.data(),
+                       model.indices.size() / 3);
+    }
+    (void)s;
+    return (int)obj.models.size();
+}
+
+// out: n_prims, n_nodes, stack_need, depth
+int hs_commit(void *p, uint32_t out[4]) {
+    Scene *s = (Scene *)p;
+    if (!rts::build_scene(s->prims, s->bvh, s->records, s->lo, s->hi, nullptr)) return -1;
+    s->view.nodes = s->bvh.nodes.data();
+    s->view.prims = s->records.data();
+    s->view.geom_material = s->geom_material.data();
+    s->view.materials = s->materials.data();
+    s->view.n_nodes = s->bvh.n_nodes;
+    s->view.n_prims = (uint32_t)s->prims.size();
+    s->view.n_geoms = (uint32_t)s->geom_material.size();
+    s->view.n_materials = (uint32_t)s->materials.size();
+    out[0] = s->view.n_prims;
+    out[1] = s->view.n_nodes;
+    out[2] = s->bvh.stack_need;
+    out[3] = s->bvh.depth;
+    return 0;
+}
+
+void hs_bounds(void *p, float lo[3], float hi[3]) {
+    Scene *s = (Scene *)p;
+    memcpy(lo, s->lo, 12);
+    memcpy(hi, s->hi, 12);
+}
+
+int hs_stack_high(void *p) { return ((Scene *)p)->stack_high; }
+
+// geometry handles and per-mesh data, for loader parity checks: returns triangle count of geometry g and copies up to
+// max_tris triangles (9 floats each, v0 v1 v2)
+size_t hs_geometry_triangles(void *p, uint32_t g, float *out, size_t max_tris) {
+    Scene *s = (Scene *)p;
+    size_t n = 0;
+    for (auto &hp : s->prims) {
+        if (hp.geom != g || hp.is_sphere) continue;
+        if (n < max_tris) {
+            memcpy(out + 9 * n, hp.a, 12);
+            memcpy(out + 9 * n + 3, hp.b, 12);
+            memcpy(out + 9 * n + 6, hp.c, 12);
+        }
+        ++n;
+    }
+    return n;
+}
+uint32_t hs_geometry_material(void *p, uint32_t g) { return ((Scene *)p)->geom_material[g]; }
+uint32_t hs_geometry_count(void *p) { return (uint32_t)((Scene *)p)->geom_material.size(); }
+uint32_t hs_material_count(void *p) { return (uint32_t)((Scene *)p)->materials.size(); }
+void hs_material_get(void *p, uint32_t i, uint32_t *kind, float out[5]) {
+    const Material &m = ((Scene *)p)->materials[i];
+    *kind = m.kind;
+    out[0] = m.r;
+    out[1] = m.g;
+    out[2] = m.b;
+    out[3] = m.ior;
+    out[4] = m.roughness;
+}
+
+void hs_intersect(void *p, const Ray *rays, Hit *hits, size_t n) {
+    Scene *s = (Scene *)p;
+    for (size_t i = 0; i < n; ++i) {
+        V3 o = mk(rays[i].org[0], rays[i].org[1], rays[i].org[2]);
+        V3 d = mk(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
+        VecStack st;
+        Closest best;
+        closest_hit(s->view, o, d, rays[i].tnear, rays[i].tfar, st, best, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        if (st.high > s->stack_high) s->stack_high = st.high;
+        HitInfo h;
+        finish_hit(s->view, o, d, best, h);
+        Hit &out = hits[i];
+        out.t = h.t;
+        out.pos[0] = h.pos.x;
+        out.pos[1] = h.pos.y;
+        out.pos[2] = h.pos.z;
+        out.n[0] = h.n.x;
+        out.n[1] = h.n.y;
+        out.n[2] = h.n.z;
+        out.uv[0] = h.u;
+        out.uv[1] = h.v;
+        out.geom_id = h.geom_id;
+        out.prim_id = h.prim_id;
+        out.mat_id = h.mat_id;
+    }
+}
+
+// One pixel sample through the same per-vertex steps the bounce kernel runs.  out as in the oracle's
+// orc_render_sample: color 0-2, normal 3-5, position 6-8, albedo 9-11, z, ray_depth, samples.  Returns rays traced.
+static uint32_t render_sample(Scene *s, const CameraView &cam, const Params &prm, uint32_t x, uint32_t y,
+                              uint32_t sample, float out[15]) {
+    memset(out, 0, 15 * sizeof(float));
+    if (prm.max_depth == 0) return 0;
+    uint32_t strata = (uint32_t)floorf(sqrtf((float)prm.spp));
+    if (strata == 0) strata = 1;
+    V3 org, dir, beta = mk(1.0f, 1.0f, 1.0f);
+    camera_ray(cam, strata, prm.seed, x, y, sample, org, dir);
+    uint32_t rays = 0;
+    float ray_depth = 0.0f;
+    V3 radiance = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t depth = 0; depth < prm.max_depth; ++depth) {
+        VecStack st;
+        Closest best;
+        closest_hit(s->view, org, dir, RT_TNEAR, INFINITY, st, best, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        if (st.high > s->stack_high) s->stack_high = st.high;
+        ++rays;
+        HitInfo h;
+        finish_hit(s->view, org, dir, best, h);
+        VertexOut vo;
+        bool cont = shade_vertex(s->view, h, prm.integrator, prm.seed, x, y, sample, depth, org, dir, beta, vo);
+        if (depth == 0) {
+            out[3] = vo.normal.x;
+            out[4] = vo.normal.y;
+            out[5] = vo.normal.z;
+            out[6] = vo.position.x;
+            out[7] = vo.position.y;
+            out[8] = vo.position.z;
+            out[9] = vo.albedo.x;
+            out[10] = vo.albedo.y;
+            out[11] = vo.albedo.z;
+            out[12] = vo.z;
+            ray_depth = 0.0f + vo.t_add;
+        } else if (h.hit && vo.t_add != 0.0f) {
+            ray_depth = ray_depth + vo.t_add;
+        }
+        if (cont && depth + 1 == prm.max_depth) {
+            vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
+            cont = false;
+        }
+        if (!cont) {
+            radiance = vo.radiance;
+            break;
+        }
+    }
+    out[0] = radiance.x;
+    out[1] = radiance.y;
+    out[2] = radiance.z;
+    out[13] = ray_depth;
+    out[14] = 1.0f;
+    return rays;
+}
+
+uint32_t hs_render_sample(void *p, const CameraView *cam, const Params *prm, uint32_t x, uint32_t y, uint32_t sample,
+                          float out[15]) {
+    return render_sample((Scene *)p, *cam, *prm, x, y, sample, out);
+}
+
+uint64_t hs_render(void *p, const CameraView *cam, const Params *prm, const uint32_t *xy, size_t npix, float *accum) {
+    Scene *s = (Scene *)p;
+    uint64_t rays = 0;
+    for (size_t i = 0; i < npix; ++i) {
+        float a[22];
+        for (int k = 0; k < 22; ++k) a[k] = accum[(size_t)k * npix + i];
+        for (uint32_t sample = prm->sample_begin; sample < prm->sample_end; ++sample) {
+            float r[15];
+            rays += render_sample(s, *cam, *prm, xy[2 * i], xy[2 * i + 1], sample, r);
+            if (prm->max_depth == 0) continue;
+            for (int ch = 0; ch < 3; ++ch) {
+                a[ch] += r[ch];
+                a[3 + ch] += r[ch] * r[ch];
+                a[6 + ch] = a[6 + ch] + 1.0f * r[ch];
+            }
+            a[9] += 1.0f;
+            for (int k = 0; k < 9; ++k) a[10 + k] = a[10 + k] + r[3 + k];
+            a[19] += r[12];
+            a[20] += r[13];
+            a[21] += 1.0f;
+        }
+        for (int k = 0; k < 22; ++k) accum[(size_t)k * npix + i] = a[k];
+    }
+    return rays;
+}
+
+} // extern "C"
