@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (bounces included) and ms/frame for the dragon scene, 1920x1080, 100 spp.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one whole frame: every rank (one process per GPU) traces all samples of its interleaved share of the 32x32
+tiles into accumulators resident in HBM, then the accumulator planes are gathered to rank 0 (RCCL).  The scene
+(mesh, BVH) is built and uploaded before the timed region.  Rank 0 prints one JSON line.
+
+The dragon mesh the reference uses is not distributed with it; unless assets/obj/dragon.obj exists the scene uses the
+deterministic 5,087,232-triangle stand-in of raytracing_amd/standin.py (config.mesh says which).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# algorithmic bytes (see DESIGN.md "Kernels"): one BVH4 node fetch, one primitive record, per-ray wavefront state
+# (ray 24 B + throughput 12 B read; the same written for the next bounce; queue entry read + written), per-path
+# state written once (first-hit outputs 44 B + radiance 12 B) and the accumulate pass (14 floats read per path).
+NODE_BYTES = 128
+PRIM_BYTES = 48
+RAY_STATE_BYTES = 80
+PATH_STATE_BYTES = 56 + 56
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "dragon-diffuse", "bunny", "cornell-box"])
+    ap.add_argument("--spp", type=int, default=100)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--max-ray-depth", type=int, default=64)
+    ap.add_argument("--tile-size", type=int, default=32)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--levels", type=int, default=5, help="subdivision levels of the stand-in dragon mesh")
+    ap.add_argument("--samples-per-pass", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-visits", action="store_true", help="skip the counting render that sizes the roofline")
+    return ap.parse_args()
+
+
+def insert_scene(name, scene, levels):
+    from raytracing_amd import scenes
+    if name == "dragon":
+        scenes.DragonScene.insert_into(scene, levels=levels)
+    elif name == "dragon-diffuse":
+        scenes.DragonScene.insert_into(scene, diffuse=True, levels=levels)
+    else:
+        scenes.AVAILABLE_SCENES[name].insert_into(scene)
+
+
+def cpu_baseline(args, camera, tiler):
+    """The CPU oracle (a port of the reference's algorithm, not Embree) on a bounded sample of the same workload:
+    every 4th tile of the frame, as many leading samples as fit the time target."""
+    from oracle import oracle as O
+    from raytracing_amd import distributed as D
+    t0 = time.time()
+    so = O.OracleScene()
+    insert_scene(args.scene, so, args.levels)
+    so.commit()
+    build_s = time.time() - t0
+    xy = D.tile_pixels(tiler, range(0, tiler.tile_count(), 4))
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    prm = O.make_params(spp=args.spp, sample_begin=0, sample_end=1, max_depth=args.max_ray_depth, seed=args.seed,
+                        threads=threads)
+    t0 = time.time()
+    _, rays1 = so.render(camera, prm, xy)
+    dt1 = max(time.time() - t0, 1e-6)
+    n = int(max(1, min(args.spp - 1, (args.cpu_seconds - dt1) / dt1)))
+    prm = O.make_params(spp=args.spp, sample_begin=1, sample_end=1 + n, max_depth=args.max_ray_depth, seed=args.seed,
+                        threads=threads)
+    t0 = time.time()
+    _, rays = so.render(camera, prm, xy)
+    dt = max(time.time() - t0, 1e-6)
+    return {
+        "value": rays / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "every 4th 32x32 tile (%d px) x samples 1..%d of %d, %.1f s; oracle BVH build %.1f s not included"
+                  % (xy.shape[0], n, args.spp, dt, build_s),
+        "rays": int(rays),
+        "seconds": dt,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the only path")
+    torch.cuda.set_device(local_rank)
+    dev_t = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev_t)
+
+    from raytracing_amd import api, types
+    from raytracing_amd import distributed as D
+
+    W, H = args.width, args.height
+    camera = types.Camera.from_dimensions(W, H)
+    tiler = api.Tiler(0, 0, W, H, args.tile_size, args.tile_size)
+    device = api.Device(local_rank)
+    t0 = time.time()
+    sg = api.HipScene(device)
+    insert_scene(args.scene, sg, args.levels)
+    t_insert = time.time() - t0
+    world_scene = sg.commit().into_world()
+    info = world_scene.info()
+    mesh = getattr(sg, "dragon_mesh", args.scene)
+
+    my_tiles = D.partition_tiles(tiler.tile_count(), world, rank)
+    xy = D.tile_pixels(tiler, my_tiles)
+    accum = torch.zeros((api.ACCUM_PLANES, xy.shape[0]), dtype=torch.float32, device=dev_t)
+    torch.cuda.synchronize()
+    film = api.Film(device, xy, accum.data_ptr())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        accum.zero_()
+        torch.cuda.synchronize()
+        st = api.render(world_scene, film, camera, args.spp, None, args.max_ray_depth, 0, args.seed,
+                        args.samples_per_pass)
+        frame = D.gather_frame(accum, xy, W, H)
+        return st, frame
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    rays = paths = 0
+    gpu_ms = bounce_ms = 0.0
+    passes = 0
+    for _ in range(args.steps):
+        st, frame = step()
+        rays += st["rays"]
+        paths += st["paths"]
+        gpu_ms += st["gpu_ms"]
+        bounce_ms += st["bounce_ms"]
+        passes += st["passes"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
+    t_cnt = torch.tensor([rays, paths], dtype=torch.int64, device=dev_t)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_cnt, op=dist.ReduceOp.SUM)
+    elapsed = float(t_el.item())
+    total_rays, total_paths = int(t_cnt[0].item()), int(t_cnt[1].item())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        ms_per_step = elapsed / steps * 1e3
+        value = total_rays / elapsed / 1e6
+        # roofline of the dominant kernel (bounce_kernel) from this rank's own launches
+        roofline = None
+        if not args.no_visits:
+            device.count_visits(True)
+            film_c = api.Film(device, xy)
+            st_c = api.render(world_scene, film_c, camera, args.spp, None, args.max_ray_depth, 0, args.seed,
+                              args.samples_per_pass)
+            nodes, tests = device.visits()
+            device.count_visits(False)
+            film_c.close()
+            n_launch = passes * args.max_ray_depth
+            alg_bytes = (nodes * NODE_BYTES + tests * PRIM_BYTES + st_c["rays"] * RAY_STATE_BYTES +
+                         st_c["paths"] * PATH_STATE_BYTES)
+            kernel_s = bounce_ms / steps / 1e3
+            achieved = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    key = "%s_%dx%d_%dspp" % (args.scene, W, H, args.spp)
+                    if key in tj:
+                        traffic = tj[key]["hbm_bytes_per_launch"]
+                except Exception:
+                    traffic = None
+            roofline = {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "bounce_kernel",
+                "launches_per_step": n_launch // steps,
+                "avg_launch_ms": bounce_ms / max(n_launch, 1),
+                "kernel_ms_per_step": bounce_ms / steps,
+                "algorithmic_bytes_per_step": alg_bytes,
+                "algorithmic_bytes_per_launch": alg_bytes / max(n_launch // steps, 1),
+                "nodes_per_ray": nodes / max(st_c["rays"], 1),
+                "prim_tests_per_ray": tests / max(st_c["rays"], 1),
+                "bytes_per_ray": alg_bytes / max(st_c["rays"], 1),
+                "note": "scene (%.0f MB nodes + %.0f MB primitives) exceeds L2 and, for the dragon, the 256 MB "
+                        "Infinity Cache only partly; fetches are 128-B node / 48-B primitive gathers"
+                        % (info["node_bytes"] / 1e6, info["prim_bytes"] / 1e6),
+            }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, camera, tiler)
+        out = {
+            "metric": "Mrays/s (incl. bounces) + ms/frame, dragon 1080p 100spp at 1/2/4/8 MI355X",
+            "value": value,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s %dx%d %d spp, path tracer, max depth %d, tile %d, seed %d" %
+                            (args.scene, W, H, args.spp, args.max_ray_depth, args.tile_size, args.seed),
+                "mesh": mesh,
+                "triangles": int(info["n_prims"]),
+                "bvh_nodes": int(info["n_nodes"]),
+                "partition": "tiles interleaved over %d rank(s), full scene replica per GPU, gather to rank 0" % world,
+            },
+            "ms_per_frame": ms_per_step,
+            "mpaths_per_s": total_paths / elapsed / 1e6,
+            "rays_per_path": total_rays / max(total_paths, 1),
+            "gpu_ms_per_step_rank0": gpu_ms / steps,
+            "scene_build_ms": info["build_ms"],
+            "scene_insert_ms": t_insert * 1e3,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    film.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,7 +7,7 @@ estimator at sizes the oracle finishes in seconds; at full size, properties that
 import numpy as np
 import pytest
 
-from conftest import bits, full_frame_xy, same_bits
+from tests.helpers import bits, full_frame_xy, same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -113,7 +113,7 @@ def test_axis_aligned_and_degenerate_rays(oracle, scene_classes, device):
     rays["tnear"] = 1e-5
     rays["tfar"] = np.inf
     rays["tfar"][-3:] = 1e-5
-    check_hits(world.intersect(rays.astype(np.float32, copy=False)), so.intersect(rays, oracle.ISECT_BRUTE))
+    check_hits(world.intersect(rays), so.intersect(rays, oracle.ISECT_BRUTE))
 
 
 def render_both(oracle, so, world, device, width, height, spp, max_depth=64, seed=0, integrator=0, xy=None,
