@@ -13,7 +13,8 @@ constexpr int BLOCK = 256;
 constexpr int STATE_PLANES = 23; // per-path SoA planes, see RenderArgs::state
 constexpr int ACCUM_PLANES = 22;
 constexpr int RESOLVE_PLANES = 15;
-constexpr uint32_t MAX_STACK = 128;
+constexpr uint32_t MAX_STACK = 160; // deepest tree the kernels accept (entries of traversal stack)
+constexpr int LDS_STACK = 24;       // stack entries kept in LDS per lane; deeper entries spill to global memory
 
 struct RayAoS {
     float org[3];
@@ -41,6 +42,7 @@ struct RenderArgs {
     uint32_t *queue[2];     // live path ids, ping-pong by bounce parity
     uint32_t *counts;       // counts[d] = live paths entering bounce d (d >= 1); zeroed before the pass
     uint32_t *work;         // work[d] = next unclaimed queue position of bounce d; zeroed before the pass
+    uint32_t *spill;        // traversal stack overflow: (stack_need - LDS_STACK) entries per launched thread
     uint32_t *visit_counters; // optional: [0] node visits, [1] primitive tests (64-bit pairs lo/hi), may be null
     uint32_t n_pixels;
     uint32_t n_paths;
@@ -51,10 +53,10 @@ struct RenderArgs {
     uint64_t seed;
 };
 
-// stack = entries of per-lane traversal stack to provide (>= the tree's need); one of 32, 64, 128.
-int launch_intersect(const rtd::SceneView &scene, const RayAoS *d_rays, HitAoS *d_hits, size_t n, uint32_t stack,
-                     void *stream);
-int launch_bounce(const RenderArgs &args, uint32_t depth, uint32_t stack, uint32_t grid_blocks, void *stream);
+// d_spill must hold max(0, stack_need - LDS_STACK) * grid_blocks * BLOCK entries (stack_need = the tree's worst case).
+int launch_intersect(const rtd::SceneView &scene, const RayAoS *d_rays, HitAoS *d_hits, size_t n, uint32_t *d_spill,
+                     uint32_t grid_blocks, void *stream);
+int launch_bounce(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream);
 int launch_accumulate(const RenderArgs &args, float *d_accum, uint32_t samples, float count_inc, void *stream);
 int launch_resolve(const float *d_accum, uint32_t n_pixels, float *d_out, int srgb, void *stream);
 

@@ -18,29 +18,40 @@ using namespace rtd;
 
 namespace rtk {
 
-template <int STACK>
-struct LdsStack {
-    uint32_t *col; // &lds[lane of block]; entry e is at col[e * BLOCK]
+// Per-lane traversal stack: the first LDS_STACK entries live in LDS, deeper ones (rare: the tree's worst case is far
+// above the typical depth) spill to a per-thread column of a global buffer sized from the committed tree.
+struct LaneStack {
+    uint32_t *col;  // &lds[thread of block]; entry e is at col[e * BLOCK]
+    uint32_t *ovf;  // &spill[global thread]; entry LDS_STACK + e is at ovf[e * ovf_stride]
+    size_t ovf_stride;
     int sp;
     __device__ __forceinline__ void push(uint32_t v) {
-        if (sp < STACK) {
+        if (sp < LDS_STACK)
             col[sp * BLOCK] = v;
-            ++sp;
-        }
+        else
+            ovf[(size_t)(sp - LDS_STACK) * ovf_stride] = v;
+        ++sp;
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
-        return col[sp * BLOCK];
+        return sp < LDS_STACK ? col[sp * BLOCK] : ovf[(size_t)(sp - LDS_STACK) * ovf_stride];
     }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
-template <int STACK>
-__global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const RayAoS *__restrict__ rays,
-                                                          HitAoS *__restrict__ hits, uint64_t n) {
-    __shared__ uint32_t lds[STACK * BLOCK];
-    LdsStack<STACK> st;
+__device__ __forceinline__ LaneStack make_stack(uint32_t *lds, uint32_t *spill) {
+    LaneStack st;
     st.col = lds + threadIdx.x;
+    st.ovf_stride = (size_t)gridDim.x * BLOCK;
+    st.ovf = spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    st.sp = 0;
+    return st;
+}
+
+__global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const RayAoS *__restrict__ rays,
+                                                          HitAoS *__restrict__ hits, uint64_t n, uint32_t *spill) {
+    __shared__ uint32_t lds[LDS_STACK * BLOCK];
+    LaneStack st = make_stack(lds, spill);
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
         const F4 *rp = reinterpret_cast<const F4 *>(rays + i);
         F4 r0 = rp[0], r1 = rp[1];
@@ -70,11 +81,9 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const
     }
 }
 
-template <int STACK>
 __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t depth) {
-    __shared__ uint32_t lds[STACK * BLOCK];
-    LdsStack<STACK> st;
-    st.col = lds + threadIdx.x;
+    __shared__ uint32_t lds[LDS_STACK * BLOCK];
+    LaneStack st = make_stack(lds, a.spill);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = (depth == 0u) ? a.n_paths : a.counts[depth];
     const uint32_t *__restrict__ q_in = a.queue[depth & 1u];
@@ -271,32 +280,18 @@ static uint32_t blocks_for(size_t n, uint32_t cap) {
     return (uint32_t)b;
 }
 
-int launch_intersect(const SceneView &scene, const RayAoS *d_rays, HitAoS *d_hits, size_t n, uint32_t stack,
-                     void *stream) {
+int launch_intersect(const SceneView &scene, const RayAoS *d_rays, HitAoS *d_hits, size_t n, uint32_t *d_spill,
+                     uint32_t grid_blocks, void *stream) {
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const uint32_t grid = blocks_for(n, 256u * 8u);
-    if (stack <= 32)
-        hipLaunchKernelGGL(intersect_kernel<32>, dim3(grid), dim3(BLOCK), 0, s, scene, d_rays, d_hits, (uint64_t)n);
-    else if (stack <= 64)
-        hipLaunchKernelGGL(intersect_kernel<64>, dim3(grid), dim3(BLOCK), 0, s, scene, d_rays, d_hits, (uint64_t)n);
-    else if (stack <= 128)
-        hipLaunchKernelGGL(intersect_kernel<128>, dim3(grid), dim3(BLOCK), 0, s, scene, d_rays, d_hits, (uint64_t)n);
-    else
-        return -1;
+    const uint32_t grid = blocks_for(n, grid_blocks);
+    hipLaunchKernelGGL(intersect_kernel, dim3(grid), dim3(BLOCK), 0, s, scene, d_rays, d_hits, (uint64_t)n, d_spill);
     return check_launch();
 }
 
-int launch_bounce(const RenderArgs &args, uint32_t depth, uint32_t stack, uint32_t grid_blocks, void *stream) {
+int launch_bounce(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (stack <= 32)
-        hipLaunchKernelGGL(bounce_kernel<32>, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
-    else if (stack <= 64)
-        hipLaunchKernelGGL(bounce_kernel<64>, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
-    else if (stack <= 128)
-        hipLaunchKernelGGL(bounce_kernel<128>, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
-    else
-        return -1;
+    hipLaunchKernelGGL(bounce_kernel, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
     return check_launch();
 }
 

@@ -58,6 +58,8 @@ struct rtmi_scene {
     rtd::F4 *d_prims = nullptr;
     uint32_t *d_geom_material = nullptr;
     rtd::Material *d_materials = nullptr;
+    uint32_t *d_spill = nullptr; // traversal stack overflow for a full resident grid
+    uint32_t grid_blocks = 0;    // resident grid the spill buffer is sized for
     rtd::SceneView view{};
 };
 
@@ -88,6 +90,8 @@ void free_scene_device(rtmi_scene *s) {
     if (s->d_prims) (void)hipFree(s->d_prims);
     if (s->d_geom_material) (void)hipFree(s->d_geom_material);
     if (s->d_materials) (void)hipFree(s->d_materials);
+    if (s->d_spill) (void)hipFree(s->d_spill);
+    s->d_spill = nullptr;
     s->d_nodes = s->d_prims = nullptr;
     s->d_geom_material = nullptr;
     s->d_materials = nullptr;
@@ -320,6 +324,15 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
     HIP_TRY(hipMalloc((void **)&scene->d_materials, scene->materials.size() * sizeof(rtd::Material)));
     HIP_TRY(hipMemcpy(scene->d_materials, scene->materials.data(), scene->materials.size() * sizeof(rtd::Material),
                       hipMemcpyHostToDevice));
+    // resident grid: LDS (LDS_STACK * BLOCK * 4 bytes per block of 160 KiB) and 8 blocks of 4 waves per CU at most
+    {
+        const uint32_t lds_per_block = rtk::LDS_STACK * rtk::BLOCK * 4u;
+        const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (160u * 1024u) / lds_per_block));
+        scene->grid_blocks = (uint32_t)dev->n_cu * per_cu;
+        const size_t deep = bvh.stack_need > (uint32_t)rtk::LDS_STACK ? bvh.stack_need - rtk::LDS_STACK : 0;
+        const size_t spill_bytes = std::max<size_t>(16, deep * scene->grid_blocks * rtk::BLOCK * sizeof(uint32_t));
+        HIP_TRY(hipMalloc((void **)&scene->d_spill, spill_bytes));
+    }
     scene->view.nodes = scene->d_nodes;
     scene->view.prims = scene->d_prims;
     scene->view.geom_material = scene->d_geom_material;
@@ -366,18 +379,13 @@ int rtmi_scene_geometry_material(const rtmi_scene *scene, uint32_t geom, uint32_
     return RTMI_OK;
 }
 
-static uint32_t stack_for(const rtmi_scene *scene) {
-    const uint32_t need = scene->info.stack_need;
-    return need <= 32 ? 32u : (need <= 64 ? 64u : 128u);
-}
-
 int rtmi_intersect_device(rtmi_scene *scene, const rtmi_ray *d_rays, rtmi_hit *d_hits, size_t n, void *hip_stream) {
     if (!scene || (n && (!d_rays || !d_hits))) return fail(RTMI_ERR_ARG, "rtmi_intersect_device: NULL argument");
     if (!scene->committed) return fail(RTMI_ERR_STATE, "scene not committed");
     if (int rc = use_device(scene->dev)) return rc;
     static_assert(sizeof(rtmi_ray) == sizeof(rtk::RayAoS) && sizeof(rtmi_hit) == sizeof(rtk::HitAoS), "layout");
     if (rtk::launch_intersect(scene->view, reinterpret_cast<const rtk::RayAoS *>(d_rays),
-                              reinterpret_cast<rtk::HitAoS *>(d_hits), n, stack_for(scene), hip_stream))
+                              reinterpret_cast<rtk::HitAoS *>(d_hits), n, scene->d_spill, scene->grid_blocks, hip_stream))
         return fail(RTMI_ERR_DEVICE, "intersect kernel launch failed");
     return RTMI_OK;
 }
@@ -516,9 +524,19 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     hipStream_t stream = dev->stream;
 
     // samples traced together per pass
-    const size_t target_paths = (size_t)8 << 20;
+    // Default: as many samples of every pixel in flight as fit a quarter of the free HBM (100 bytes of state per
+    // path), so that the long, thin tail of deep bounces is paid once per frame and not once per small pass.
     uint32_t spp_pass = params->samples_per_pass;
-    if (spp_pass == 0) spp_pass = (uint32_t)std::max<size_t>(1, target_paths / npix);
+    if (spp_pass == 0) {
+        size_t free_b = 0, total_b = 0;
+        size_t target_paths = (size_t)8 << 20;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            size_t have = film->cap_paths * (rtk::STATE_PLANES * sizeof(float) + 2 * sizeof(uint32_t));
+            target_paths = std::max(target_paths, (free_b + have) / 4 / 100);
+        }
+        target_paths = std::min<size_t>(target_paths, (size_t)1 << 28);
+        spp_pass = (uint32_t)std::max<size_t>(1, target_paths / npix);
+    }
     spp_pass = std::min(spp_pass, n_samples);
     if ((size_t)spp_pass * npix >= (1ull << 31)) spp_pass = (uint32_t)std::max<size_t>(1, ((1ull << 31) - 1) / npix);
     const size_t max_paths = (size_t)spp_pass * npix;
@@ -571,12 +589,8 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.integrator = params->integrator;
     a.seed = params->seed;
 
-    const uint32_t stack = stack_for(scene);
-    // resident grid: LDS bounds the blocks per CU (stack * BLOCK * 4 bytes each of 160 KiB)
-    const uint32_t lds_per_block = stack * rtk::BLOCK * 4u;
-    uint32_t blocks_per_cu = std::min<uint32_t>(8u, (160u * 1024u) / lds_per_block);
-    if (blocks_per_cu == 0) blocks_per_cu = 1;
-    const uint32_t full_grid = (uint32_t)dev->n_cu * blocks_per_cu;
+    a.spill = scene->d_spill;
+    const uint32_t full_grid = scene->grid_blocks;
 
     hipEvent_t ev_begin, ev_end;
     HIP_TRY(hipEventCreate(&ev_begin));
@@ -595,7 +609,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         const uint32_t grid = std::min<uint32_t>(full_grid, (a.n_paths + rtk::BLOCK - 1) / rtk::BLOCK);
         (void)hipEventRecord(ev_pass[2 * pass], stream);
         for (uint32_t depth = 0; depth < params->max_depth; ++depth) {
-            if (rtk::launch_bounce(a, depth, stack, grid, stream)) {
+            if (rtk::launch_bounce(a, depth, grid, stream)) {
                 rc = fail(RTMI_ERR_DEVICE, "bounce kernel launch failed");
                 break;
             }

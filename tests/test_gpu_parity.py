@@ -305,3 +305,29 @@ def test_full_size_properties(oracle, scene_classes, device):
     sub = np.arange(0, xy.shape[0], 997)
     want, _ = so.render(cam, oracle.make_params(spp=spp), xy[sub])
     assert same_bits(whole[:, sub], want).all()
+
+
+def test_deep_traversal_stack_spills(oracle, device):
+    """60,000 large overlapping triangles: rays through the soup need more stack entries than the kernels keep in LDS
+    (24 per lane), so the deeper entries go through the global spill buffer.  Hits must still equal brute force."""
+    from raytracing_amd import api
+    rng = np.random.default_rng(5)
+    n = 60000
+    c = rng.uniform(-1, 1, (n, 3))
+    v = (c[:, None, :] + rng.normal(scale=1.5, size=(n, 3, 3))).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    so = oracle.OracleScene()
+    so.insert_mesh(0, v.reshape(-1, 3), idx)
+    so.commit()
+    sg = api.HipScene(device)
+    sg.insert_mesh(0, v.reshape(-1, 3), idx)
+    world = sg.commit().into_world()
+    assert world.info()["stack_need"] > 24
+    m = 4096
+    rays = np.zeros(m, dtype=oracle.RAY_DTYPE)
+    d = rng.normal(size=(m, 3))
+    rays["dir"] = d / np.linalg.norm(d, axis=1)[:, None]
+    rays["org"] = rng.uniform(-1, 1, (m, 3)) - 3 * rays["dir"]
+    rays["tnear"] = 1e-5
+    rays["tfar"] = np.inf
+    check_hits(world.intersect(rays), so.intersect(rays, oracle.ISECT_BRUTE))
