@@ -81,10 +81,17 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const
     }
 }
 
+// Lanes refill themselves: a lane whose ray has finished traversal shades it, publishes the continuation and takes the
+// next queue entry, while the other lanes of the wave keep their rays.  To keep both halves efficient the wave only
+// leaves the traversal loop when fewer than REFILL_BELOW lanes are still traversing (or the queue is drained and
+// nothing is left), so traversal runs with most lanes busy and shading runs for a batch of lanes at a time.
+constexpr int REFILL_BELOW = 44;
+
 __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t depth) {
     __shared__ uint32_t lds[LDS_STACK * BLOCK];
     LaneStack st = make_stack(lds, a.spill);
     const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t n_in = (depth == 0u) ? a.n_paths : a.counts[depth];
     const uint32_t *__restrict__ q_in = a.queue[depth & 1u];
     uint32_t *__restrict__ q_out = a.queue[(depth + 1u) & 1u];
@@ -93,35 +100,19 @@ __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t de
     uint32_t nodes = 0, tests = 0;
     const bool count_visits = a.visit_counters != nullptr;
 
+    bool has_ray = false;
+    bool drained = false; // wave-uniform: the queue has no unclaimed entries left
+    uint32_t pid = 0, x = 0, y = 0, sample = 0;
+    V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f), beta = mk(0.0f, 0.0f, 0.0f);
+    Trav tr;
+    tr.cur = RT_EMPTY;
+
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&a.work[depth], 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n_in) break;
-        const uint32_t i = base + lane;
-        const bool active = i < n_in;
+        // ---- shade the lanes whose traversal is complete
         bool alive = false;
-        uint32_t pid = 0;
-        if (active) {
-            pid = (depth == 0u) ? i : q_in[i];
-            const uint32_t pix = pid % a.n_pixels;
-            const uint32_t sample = a.sample_base + pid / a.n_pixels;
-            const uint32_t x = a.pixels[2 * pix], y = a.pixels[2 * pix + 1];
-            V3 org, dir, beta;
-            if (depth == 0u) {
-                camera_ray(a.camera, a.strata, a.seed, x, y, sample, org, dir);
-                beta = mk(1.0f, 1.0f, 1.0f);
-            } else {
-                org = mk(S[0 * P + pid], S[1 * P + pid], S[2 * P + pid]);
-                dir = mk(S[3 * P + pid], S[4 * P + pid], S[5 * P + pid]);
-                beta = mk(S[6 * P + pid], S[7 * P + pid], S[8 * P + pid]);
-            }
-            st.sp = 0;
-            Closest best;
-            closest_hit(a.scene, org, dir, RT_TNEAR, INFINITY, st, best, count_visits ? &nodes : nullptr,
-                        count_visits ? &tests : nullptr);
+        if (has_ray && tr.cur == RT_EMPTY) {
             HitInfo h;
-            finish_hit(a.scene, org, dir, best, h);
+            finish_hit(a.scene, org, dir, tr.best, h);
             VertexOut vo;
             bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, x, y, sample, depth, org, dir, beta, vo);
             if (depth == 0u) {
@@ -160,17 +151,55 @@ __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t de
                 S[10 * P + pid] = vo.radiance.y;
                 S[11 * P + pid] = vo.radiance.z;
             }
+            has_ray = false;
         }
-        // compaction: one atomic per wave, lanes ranked by the ballot
-        const unsigned long long mask = __ballot(alive);
-        if (mask != 0ull) {
+        // ---- publish survivors: one atomic per wave, lanes ranked by the ballot
+        const unsigned long long amask = __ballot(alive);
+        if (amask != 0ull) {
             uint32_t obase = 0;
-            if (lane == 0) obase = atomicAdd(&a.counts[depth + 1u], (uint32_t)__popcll(mask));
+            if (lane == 0) obase = atomicAdd(&a.counts[depth + 1u], (uint32_t)__popcll(amask));
             obase = __builtin_amdgcn_readfirstlane(obase);
-            if (alive) {
-                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                q_out[obase + rank] = pid;
+            if (alive) q_out[obase + (uint32_t)__popcll(amask & below)] = pid;
+        }
+        // ---- refill idle lanes from the queue: one atomic per wave
+        if (!drained) {
+            const unsigned long long nmask = __ballot(!has_ray);
+            const uint32_t want = (uint32_t)__popcll(nmask);
+            if (want != 0u) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&a.work[depth], want);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + want >= n_in) drained = true;
+                const uint32_t i = base + (uint32_t)__popcll(nmask & below);
+                if (!has_ray && i < n_in) {
+                    pid = (depth == 0u) ? i : q_in[i];
+                    const uint32_t pix = pid % a.n_pixels;
+                    sample = a.sample_base + pid / a.n_pixels;
+                    x = a.pixels[2 * pix];
+                    y = a.pixels[2 * pix + 1];
+                    if (depth == 0u) {
+                        camera_ray(a.camera, a.strata, a.seed, x, y, sample, org, dir);
+                        beta = mk(1.0f, 1.0f, 1.0f);
+                    } else {
+                        org = mk(S[0 * P + pid], S[1 * P + pid], S[2 * P + pid]);
+                        dir = mk(S[3 * P + pid], S[4 * P + pid], S[5 * P + pid]);
+                        beta = mk(S[6 * P + pid], S[7 * P + pid], S[8 * P + pid]);
+                    }
+                    st.sp = 0;
+                    trav_begin(a.scene, dir, INFINITY, tr);
+                    has_ray = true;
+                }
             }
+        }
+        if (__ballot(has_ray) == 0ull) break;
+        // ---- traverse while enough lanes are busy (all the way once the queue is drained)
+        const int keep_going = drained ? 1 : REFILL_BELOW;
+        for (;;) {
+            const bool busy = has_ray && tr.cur != RT_EMPTY;
+            if ((int)__popcll(__ballot(busy)) < keep_going) break;
+            if (busy)
+                trav_round(a.scene, org, dir, RT_TNEAR, tr, st, count_visits ? &nodes : nullptr,
+                           count_visits ? &tests : nullptr);
         }
     }
     if (count_visits) {

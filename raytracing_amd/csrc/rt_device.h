@@ -545,22 +545,39 @@ RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnea
 // Reciprocal that never produces inf, so that 0 * inv is 0 and not NaN in the slab test.
 RT_DEV float safe_rcp(float d) { return 1.0f / (fabsf(d) > 1e-20f ? d : copysignf(1e-20f, d)); }
 
-// Closest hit of o + t d over (tnear, tfar] in the 4-wide BVH.  `Stack` offers push(uint32_t) / pop() / empty();
-// the tree's worst-case stack need is known at commit time and the kernels are instantiated with enough room.
-// Visit counters (may be null) count node and primitive fetches.
+// Traversal state of one ray: reciprocal direction, the node or leaf to visit next (RT_EMPTY = finished) and the best
+// candidate so far.  The stack is separate (`Stack` offers push(uint32_t) / pop() / empty()); the tree's worst-case
+// stack need is known at commit time and the kernels provide that much room.
+struct Trav {
+    float ix, iy, iz;
+    uint32_t cur;
+    Closest best;
+};
+
+RT_DEV void trav_begin(const SceneView &sv, V3 d, float tfar, Trav &tr) {
+    tr.best.t = tfar;
+    tr.best.gidx = RT_EMPTY;
+    tr.best.slot = 0;
+    tr.best.u = tr.best.v = 0.0f;
+    tr.best.ng = mk(0.0f, 0.0f, 0.0f);
+    tr.ix = safe_rcp(d.x);
+    tr.iy = safe_rcp(d.y);
+    tr.iz = safe_rcp(d.z);
+    tr.cur = sv.n_nodes == 0 ? RT_EMPTY : 0u; // root
+}
+
+// One round of traversal: descend through inner nodes until this lane holds a leaf (or is finished), then work through
+// leaves until it holds an inner node again.  Run by all lanes of a wave together, the two phases keep the lanes on
+// the same code.  Visit counters (may be null) count node and primitive fetches.
 template <class Stack>
-RT_DEV void closest_hit(const SceneView &sv, V3 o, V3 d, float tnear, float tfar, Stack &st, Closest &best,
-                        uint32_t *node_visits, uint32_t *prim_tests) {
-    best.t = tfar;
-    best.gidx = RT_EMPTY;
-    best.slot = 0;
-    best.u = best.v = 0.0f;
-    best.ng = mk(0.0f, 0.0f, 0.0f);
-    if (sv.n_nodes == 0) return;
-    const float ix = safe_rcp(d.x), iy = safe_rcp(d.y), iz = safe_rcp(d.z);
-    uint32_t cur = 0; // root
-    for (;;) {
-        if (!(cur & RT_LEAF)) {
+RT_DEV void trav_round(const SceneView &sv, V3 o, V3 d, float tnear, Trav &tr, Stack &st, uint32_t *node_visits,
+                       uint32_t *prim_tests) {
+    const float ix = tr.ix, iy = tr.iy, iz = tr.iz;
+    Closest &best = tr.best;
+    uint32_t cur = tr.cur;
+    {
+        // RT_EMPTY carries the leaf bit, so a finished lane falls through both loops
+        while (!(cur & RT_LEAF)) {
             const F4 *n = sv.nodes + (size_t)cur * RT_NODE_F4;
             F4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5];
             F4 cf = n[6];
@@ -604,25 +621,35 @@ RT_DEV void closest_hit(const SceneView &sv, V3 o, V3 d, float tnear, float tfar
             RT_CSWAP(a1, i1, a2, i2)
 #undef RT_CSWAP
             if (i0 == RT_EMPTY) {
-                if (st.empty()) break;
-                cur = st.pop();
-                continue;
+                cur = st.empty() ? RT_EMPTY : st.pop();
+            } else {
+                if (i3 != RT_EMPTY) st.push(i3);
+                if (i2 != RT_EMPTY) st.push(i2);
+                if (i1 != RT_EMPTY) st.push(i1);
+                cur = i0;
             }
-            if (i3 != RT_EMPTY) st.push(i3);
-            if (i2 != RT_EMPTY) st.push(i2);
-            if (i1 != RT_EMPTY) st.push(i1);
-            cur = i0;
-        } else {
+        }
+        while (cur != RT_EMPTY && (cur & RT_LEAF)) {
             uint32_t first = cur & 0x0FFFFFFFu;
             uint32_t count = ((cur >> 28) & 7u) + 1u;
             for (uint32_t k = 0; k < count; ++k) {
                 if (prim_tests) ++*prim_tests;
                 test_prim(sv, first + k, o, d, tnear, best);
             }
-            if (st.empty()) break;
-            cur = st.pop();
+            cur = st.empty() ? RT_EMPTY : st.pop();
         }
     }
+    tr.cur = cur;
+}
+
+// Closest hit of o + t d over (tnear, tfar] in the 4-wide BVH.
+template <class Stack>
+RT_DEV void closest_hit(const SceneView &sv, V3 o, V3 d, float tnear, float tfar, Stack &st, Closest &best,
+                        uint32_t *node_visits, uint32_t *prim_tests) {
+    Trav tr;
+    trav_begin(sv, d, tfar, tr);
+    while (tr.cur != RT_EMPTY) trav_round(sv, o, d, tnear, tr, st, node_visits, prim_tests);
+    best = tr.best;
 }
 
 struct HitInfo {

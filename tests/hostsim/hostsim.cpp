@@ -300,4 +300,34 @@ uint64_t hs_render(void *p, const CameraView *cam, const Params *prm, const uint
     return rays;
 }
 
+// Per-bounce work statistics over a pixel list: out[3 * d + 0..2] = rays, node visits, primitive tests at bounce d.
+void hs_depth_stats(void *p, const CameraView *cam, const Params *prm, const uint32_t *xy, size_t npix, uint32_t max_d,
+                    double *out) {
+    Scene *s = (Scene *)p;
+    uint32_t strata = (uint32_t)floorf(sqrtf((float)prm->spp));
+    if (strata == 0) strata = 1;
+    for (size_t i = 0; i < npix; ++i)
+        for (uint32_t sample = prm->sample_begin; sample < prm->sample_end; ++sample) {
+            V3 org, dir, beta = mk(1.0f, 1.0f, 1.0f);
+            camera_ray(*cam, strata, prm->seed, xy[2 * i], xy[2 * i + 1], sample, org, dir);
+            for (uint32_t depth = 0; depth < prm->max_depth; ++depth) {
+                VecStack st;
+                Closest best;
+                uint32_t nodes = 0, tests = 0;
+                closest_hit(s->view, org, dir, RT_TNEAR, INFINITY, st, best, &nodes, &tests);
+                if (depth < max_d) {
+                    out[3 * depth] += 1;
+                    out[3 * depth + 1] += nodes;
+                    out[3 * depth + 2] += tests;
+                }
+                HitInfo h;
+                finish_hit(s->view, org, dir, best, h);
+                VertexOut vo;
+                if (!shade_vertex(s->view, h, prm->integrator, prm->seed, xy[2 * i], xy[2 * i + 1], sample, depth, org,
+                                  dir, beta, vo))
+                    break;
+            }
+        }
+}
+
 } // extern "C"
