@@ -154,7 +154,7 @@ def main():
     t0 = time.perf_counter()
     rays = paths = 0
     gpu_ms = bounce_ms = 0.0
-    passes = 0
+    passes = launches = 0
     for _ in range(args.steps):
         st, frame = step()
         rays += st["rays"]
@@ -162,6 +162,7 @@ def main():
         gpu_ms += st["gpu_ms"]
         bounce_ms += st["bounce_ms"]
         passes += st["passes"]
+        launches += st["bounce_launches"]
     barrier()
     elapsed = time.perf_counter() - t0
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
@@ -186,7 +187,7 @@ def main():
             nodes, tests = device.visits()
             device.count_visits(False)
             film_c.close()
-            n_launch = passes * args.max_ray_depth
+            n_launch = launches
             alg_bytes = (nodes * NODE_BYTES + tests * PRIM_BYTES + st_c["rays"] * RAY_STATE_BYTES +
                          st_c["paths"] * PATH_STATE_BYTES)
             kernel_s = bounce_ms / steps / 1e3

@@ -110,7 +110,9 @@ typedef struct rtmi_render_stats {
     uint32_t passes; /* wavefront passes run */
     uint32_t max_bounces; /* deepest bounce that still had live paths */
     float gpu_ms;    /* device time of the call, from HIP events on the render stream */
-    float bounce_ms; /* device time spent in the bounce kernel alone */
+    float bounce_ms; /* of which: between the first and the last bounce-kernel launch of every pass */
+    uint32_t bounce_launches; /* bounce-kernel launches issued */
+    uint32_t reserved;
 } rtmi_render_stats;
 
 typedef struct rtmi_scene_info {

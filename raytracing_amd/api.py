@@ -382,14 +382,15 @@ class Executor:
         xy = np.concatenate([t.pixels() for t in tile_list], 0) if tile_list else np.zeros((0, 2), np.uint32)
         offsets = np.cumsum([0] + [len(t) for t in tile_list])
         film = Film(world.scene.device, xy)
-        stats = {"rays": 0, "paths": 0, "passes": 0, "gpu_ms": 0.0, "bounce_ms": 0.0, "max_bounces": 0}
+        stats = {"rays": 0, "paths": 0, "passes": 0, "gpu_ms": 0.0, "bounce_ms": 0.0, "max_bounces": 0,
+                 "bounce_launches": 0}
         try:
             cur = sample_range.start
             while cur < sample_range.stop:
                 n = min(batch_size, sample_range.stop - cur) if batch_size else sample_range.stop - cur
                 st = render(world, film, self.camera, self.spp, range(cur, cur + n), self.max_depth,
                             INTEGRATORS[self.integrator], self.seed)
-                for k in ("rays", "paths", "passes", "gpu_ms", "bounce_ms"):
+                for k in ("rays", "paths", "passes", "gpu_ms", "bounce_ms", "bounce_launches"):
                     stats[k] += st[k]
                 stats["max_bounces"] = max(stats["max_bounces"], st["max_bounces"])
                 cur += n

@@ -14,6 +14,9 @@ constexpr int STATE_PLANES = 23; // per-path SoA planes, see RenderArgs::state
 constexpr int ACCUM_PLANES = 22;
 constexpr int RESOLVE_PLANES = 15;
 constexpr uint32_t MAX_STACK = 160; // deepest tree the kernels accept (entries of traversal stack)
+constexpr int PIXEL_BLOCK = 64;     // pixels whose samples are adjacent in path-id space (one wave of primary rays)
+constexpr int SEGMENTS = 8;         // queue segments, one per XCD (each XCD has its own L2)
+constexpr int COUNTER_STRIDE = 64;  // uint32 slots between two counters: every counter has a 256-byte line to itself
 constexpr int LDS_STACK = 24;       // stack entries kept in LDS per lane; deeper entries spill to global memory
 
 struct RayAoS {
@@ -30,8 +33,14 @@ struct HitAoS {
     uint32_t geom_id, prim_id, mat_id;
 };
 
-// Arguments of one wavefront pass: `samples` consecutive samples of each of `n_pixels` pixels, path id
-// pid = s * n_pixels + pixel, n_paths = samples * n_pixels.
+// Arguments of one wavefront pass: `samples` consecutive samples of each of `n_pixels` pixels.
+//
+// Path ids keep all samples of a 64-pixel block together: pid = ((block * samples) + s) * 64 + p for pixel
+// block * 64 + p, so n_paths = n_blocks * 64 * samples (pixels past n_pixels in the last block are never started).
+// Work is split into SEGMENTS segments, block b belonging to segment b % SEGMENTS; every segment has its own queue
+// region, counters and cursor.  A wave starts on the segment of the XCD it runs on and appends survivors to the
+// segment they came from, so the rays one XCD's L2 sees at any time come from a few neighbouring pixel blocks, bounce
+// after bounce; drained waves move on to the other segments so no XCD idles.
 struct RenderArgs {
     rtd::SceneView scene;
     rtd::CameraView camera;
@@ -39,13 +48,18 @@ struct RenderArgs {
     float *state;           // STATE_PLANES planes of n_paths floats:
                             //   0-2 origin, 3-5 direction, 6-8 beta, 9-11 radiance, 12-14 normal, 15-17 position,
                             //   18-20 albedo, 21 z, 22 ray_depth
-    uint32_t *queue[2];     // live path ids, ping-pong by bounce parity
-    uint32_t *counts;       // counts[d] = live paths entering bounce d (d >= 1); zeroed before the pass
-    uint32_t *work;         // work[d] = next unclaimed queue position of bounce d; zeroed before the pass
+    uint32_t *queue[2];     // live path ids, ping-pong by bounce parity; segment x at queue[.] + x * seg_cap
+    uint32_t *counts;       // counts[(d * SEGMENTS + x) * COUNTER_STRIDE] = live paths of segment x entering bounce d
+                            // (d >= 1); zeroed before the pass
+    uint32_t *work;         // work[(d * SEGMENTS + x) * COUNTER_STRIDE] = next unclaimed position of that queue; zeroed
     uint32_t *spill;        // traversal stack overflow: (stack_need - LDS_STACK) entries per launched thread
     uint32_t *visit_counters; // optional: [0] node visits, [1] primitive tests (64-bit pairs lo/hi), may be null
     uint32_t n_pixels;
-    uint32_t n_paths;
+    uint32_t n_blocks;    // ceil(n_pixels / PIXEL_BLOCK)
+    uint32_t samples;     // samples of each pixel in this pass
+    uint32_t seg_cap;     // queue entries per segment
+    uint32_t n_paths;     // n_blocks * PIXEL_BLOCK * samples
+    uint32_t claim;       // queue entries a wave claims with one atomic (a multiple of 64)
     uint32_t sample_base; // first sample index of the pass
     uint32_t strata;      // floor(sqrt(spp))
     uint32_t max_depth;
@@ -57,7 +71,7 @@ struct RenderArgs {
 int launch_intersect(const rtd::SceneView &scene, const RayAoS *d_rays, HitAoS *d_hits, size_t n, uint32_t *d_spill,
                      uint32_t grid_blocks, void *stream);
 int launch_bounce(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream);
-int launch_accumulate(const RenderArgs &args, float *d_accum, uint32_t samples, float count_inc, void *stream);
+int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, void *stream);
 int launch_resolve(const float *d_accum, uint32_t n_pixels, float *d_out, int srgb, void *stream);
 
 } // namespace rtk

@@ -87,119 +87,178 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const
 // nothing is left), so traversal runs with most lanes busy and shading runs for a batch of lanes at a time.
 constexpr int REFILL_BELOW = 44;
 
+// XCC_ID hardware register (bits 3:0): the XCD this wave runs on.  Used for locality only, never for correctness.
+__device__ __forceinline__ uint32_t xcd_of_wave() {
+    return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (uint32_t)(SEGMENTS - 1);
+}
+
 __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t depth) {
     __shared__ uint32_t lds[LDS_STACK * BLOCK];
     LaneStack st = make_stack(lds, a.spill);
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const uint32_t n_in = (depth == 0u) ? a.n_paths : a.counts[depth];
-    const uint32_t *__restrict__ q_in = a.queue[depth & 1u];
-    uint32_t *__restrict__ q_out = a.queue[(depth + 1u) & 1u];
     const size_t P = a.n_paths;
     float *__restrict__ S = a.state;
     uint32_t nodes = 0, tests = 0;
     const bool count_visits = a.visit_counters != nullptr;
+    const uint32_t per_block = a.samples * (uint32_t)PIXEL_BLOCK; // paths of one pixel block
+    const uint32_t home = xcd_of_wave();
 
-    bool has_ray = false;
-    bool drained = false; // wave-uniform: the queue has no unclaimed entries left
-    uint32_t pid = 0, x = 0, y = 0, sample = 0;
-    V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f), beta = mk(0.0f, 0.0f, 0.0f);
-    Trav tr;
-    tr.cur = RT_EMPTY;
+    for (uint32_t turn = 0; turn < (uint32_t)SEGMENTS; ++turn) {
+        const uint32_t seg = (home + turn) & (uint32_t)(SEGMENTS - 1);
+        // blocks seg, seg + SEGMENTS, ... belong to this segment
+        const uint32_t seg_blocks = a.n_blocks > seg ? (a.n_blocks - seg + (uint32_t)SEGMENTS - 1u) / (uint32_t)SEGMENTS : 0u;
+        const uint32_t n_in =
+            (depth == 0u) ? seg_blocks * per_block : a.counts[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE];
+        const uint32_t *__restrict__ q_in = a.queue[depth & 1u] + (size_t)seg * a.seg_cap;
+        uint32_t *__restrict__ q_out = a.queue[(depth + 1u) & 1u] + (size_t)seg * a.seg_cap;
+        uint32_t *cursor = &a.work[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE];
+        uint32_t *out_count = &a.counts[(size_t)((depth + 1u) * SEGMENTS + seg) * COUNTER_STRIDE];
+        uint32_t c_next = 0, c_end = 0; // wave-uniform: the part of the queue this wave has claimed and not yet used
 
-    for (;;) {
-        // ---- shade the lanes whose traversal is complete
-        bool alive = false;
-        if (has_ray && tr.cur == RT_EMPTY) {
-            HitInfo h;
-            finish_hit(a.scene, org, dir, tr.best, h);
-            VertexOut vo;
-            bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, x, y, sample, depth, org, dir, beta, vo);
-            if (depth == 0u) {
-                S[12 * P + pid] = vo.normal.x;
-                S[13 * P + pid] = vo.normal.y;
-                S[14 * P + pid] = vo.normal.z;
-                S[15 * P + pid] = vo.position.x;
-                S[16 * P + pid] = vo.position.y;
-                S[17 * P + pid] = vo.position.z;
-                S[18 * P + pid] = vo.albedo.x;
-                S[19 * P + pid] = vo.albedo.y;
-                S[20 * P + pid] = vo.albedo.z;
-                S[21 * P + pid] = vo.z;
-                S[22 * P + pid] = 0.0f + vo.t_add;
-            } else if (h.hit && vo.t_add != 0.0f) {
-                S[22 * P + pid] = S[22 * P + pid] + vo.t_add;
+        bool has_ray = false;
+        bool drained = n_in == 0u; // wave-uniform: the segment has no unclaimed entries left
+        uint32_t pid = 0, x = 0, y = 0, sample = 0;
+        V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f), beta = mk(0.0f, 0.0f, 0.0f);
+        Trav tr;
+        tr.cur = RT_EMPTY;
+
+        for (;;) {
+            // ---- shade the lanes whose traversal is complete
+            bool alive = false;
+            if (has_ray && tr.cur == RT_EMPTY) {
+                HitInfo h;
+                finish_hit(a.scene, org, dir, tr.best, h);
+                VertexOut vo;
+                bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, x, y, sample, depth, org, dir, beta, vo);
+                if (depth == 0u) {
+                    S[12 * P + pid] = vo.normal.x;
+                    S[13 * P + pid] = vo.normal.y;
+                    S[14 * P + pid] = vo.normal.z;
+                    S[15 * P + pid] = vo.position.x;
+                    S[16 * P + pid] = vo.position.y;
+                    S[17 * P + pid] = vo.position.z;
+                    S[18 * P + pid] = vo.albedo.x;
+                    S[19 * P + pid] = vo.albedo.y;
+                    S[20 * P + pid] = vo.albedo.z;
+                    S[21 * P + pid] = vo.z;
+                    S[22 * P + pid] = 0.0f + vo.t_add;
+                } else if (h.hit && vo.t_add != 0.0f) {
+                    S[22 * P + pid] = S[22 * P + pid] + vo.t_add;
+                }
+                if (cont && depth + 1u == a.max_depth) {
+                    // the next vertex would be at the depth limit: it contributes beta * 0 (pathtracing.rs:24-26)
+                    vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
+                    cont = false;
+                }
+                if (cont) {
+                    S[0 * P + pid] = org.x;
+                    S[1 * P + pid] = org.y;
+                    S[2 * P + pid] = org.z;
+                    S[3 * P + pid] = dir.x;
+                    S[4 * P + pid] = dir.y;
+                    S[5 * P + pid] = dir.z;
+                    S[6 * P + pid] = beta.x;
+                    S[7 * P + pid] = beta.y;
+                    S[8 * P + pid] = beta.z;
+                    alive = true;
+                } else {
+                    S[9 * P + pid] = vo.radiance.x;
+                    S[10 * P + pid] = vo.radiance.y;
+                    S[11 * P + pid] = vo.radiance.z;
+                }
+                has_ray = false;
             }
-            if (cont && depth + 1u == a.max_depth) {
-                // the next vertex would be at the depth limit: it contributes beta * 0 (pathtracing.rs:24-26)
-                vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
-                cont = false;
+            // ---- publish survivors: one atomic per wave, lanes ranked by the ballot
+            const unsigned long long amask = __ballot(alive);
+            if (amask != 0ull) {
+                uint32_t obase = 0;
+                if (lane == 0) obase = atomicAdd(out_count, (uint32_t)__popcll(amask));
+                obase = __builtin_amdgcn_readfirstlane(obase);
+                if (alive) q_out[obase + (uint32_t)__popcll(amask & below)] = pid;
             }
-            if (cont) {
-                S[0 * P + pid] = org.x;
-                S[1 * P + pid] = org.y;
-                S[2 * P + pid] = org.z;
-                S[3 * P + pid] = dir.x;
-                S[4 * P + pid] = dir.y;
-                S[5 * P + pid] = dir.z;
-                S[6 * P + pid] = beta.x;
-                S[7 * P + pid] = beta.y;
-                S[8 * P + pid] = beta.z;
-                alive = true;
-            } else {
-                S[9 * P + pid] = vo.radiance.x;
-                S[10 * P + pid] = vo.radiance.y;
-                S[11 * P + pid] = vo.radiance.z;
-            }
-            has_ray = false;
-        }
-        // ---- publish survivors: one atomic per wave, lanes ranked by the ballot
-        const unsigned long long amask = __ballot(alive);
-        if (amask != 0ull) {
-            uint32_t obase = 0;
-            if (lane == 0) obase = atomicAdd(&a.counts[depth + 1u], (uint32_t)__popcll(amask));
-            obase = __builtin_amdgcn_readfirstlane(obase);
-            if (alive) q_out[obase + (uint32_t)__popcll(amask & below)] = pid;
-        }
-        // ---- refill idle lanes from the queue: one atomic per wave
-        if (!drained) {
-            const unsigned long long nmask = __ballot(!has_ray);
-            const uint32_t want = (uint32_t)__popcll(nmask);
-            if (want != 0u) {
+            // ---- refill idle lanes from the wave's claimed range; claim the next a.claim entries with one atomic
+            // when the range is used up
+            if (c_next == c_end && !drained) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&a.work[depth], want);
+                if (lane == 0) base = atomicAdd(cursor, a.claim);
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (base + want >= n_in) drained = true;
-                const uint32_t i = base + (uint32_t)__popcll(nmask & below);
-                if (!has_ray && i < n_in) {
-                    pid = (depth == 0u) ? i : q_in[i];
-                    const uint32_t pix = pid % a.n_pixels;
-                    sample = a.sample_base + pid / a.n_pixels;
-                    x = a.pixels[2 * pix];
-                    y = a.pixels[2 * pix + 1];
-                    if (depth == 0u) {
-                        camera_ray(a.camera, a.strata, a.seed, x, y, sample, org, dir);
-                        beta = mk(1.0f, 1.0f, 1.0f);
-                    } else {
-                        org = mk(S[0 * P + pid], S[1 * P + pid], S[2 * P + pid]);
-                        dir = mk(S[3 * P + pid], S[4 * P + pid], S[5 * P + pid]);
-                        beta = mk(S[6 * P + pid], S[7 * P + pid], S[8 * P + pid]);
-                    }
-                    st.sp = 0;
-                    trav_begin(a.scene, dir, INFINITY, tr);
-                    has_ray = true;
+                if (base >= n_in) {
+                    drained = true;
+                } else {
+                    c_next = base;
+                    c_end = min(base + a.claim, n_in);
+                    if (c_end == n_in) drained = true;
                 }
             }
-        }
-        if (__ballot(has_ray) == 0ull) break;
-        // ---- traverse while enough lanes are busy (all the way once the queue is drained)
-        const int keep_going = drained ? 1 : REFILL_BELOW;
-        for (;;) {
-            const bool busy = has_ray && tr.cur != RT_EMPTY;
-            if ((int)__popcll(__ballot(busy)) < keep_going) break;
-            if (busy)
-                trav_round(a.scene, org, dir, RT_TNEAR, tr, st, count_visits ? &nodes : nullptr,
-                           count_visits ? &tests : nullptr);
+            if (c_next != c_end) {
+                const unsigned long long nmask = __ballot(!has_ray);
+                const uint32_t i = c_next + (uint32_t)__popcll(nmask & below);
+                const bool take = !has_ray && i < c_end;
+                c_next = min(c_end, c_next + (uint32_t)__popcll(nmask));
+                if (take) {
+                    bool valid = true;
+                    uint32_t pix;
+                    if (depth == 0u) {
+                        // entry i of the segment: local block i / per_block, then sample-major inside the block
+                        const uint32_t lb = i / per_block, rem = i - lb * per_block;
+                        const uint32_t blk = lb * (uint32_t)SEGMENTS + seg;
+                        const uint32_t s_local = rem / (uint32_t)PIXEL_BLOCK, p = rem % (uint32_t)PIXEL_BLOCK;
+                        pix = blk * (uint32_t)PIXEL_BLOCK + p;
+                        pid = blk * per_block + rem;
+                        sample = a.sample_base + s_local;
+                        valid = pix < a.n_pixels;
+                    } else {
+                        pid = q_in[i];
+                        const uint32_t blk = pid / per_block, rem = pid - blk * per_block;
+                        pix = blk * (uint32_t)PIXEL_BLOCK + rem % (uint32_t)PIXEL_BLOCK;
+                        sample = a.sample_base + rem / (uint32_t)PIXEL_BLOCK;
+                    }
+                    if (valid) {
+                        x = a.pixels[2 * pix];
+                        y = a.pixels[2 * pix + 1];
+                        if (depth == 0u) {
+                            camera_ray(a.camera, a.strata, a.seed, x, y, sample, org, dir);
+                            beta = mk(1.0f, 1.0f, 1.0f);
+                        } else {
+                            org = mk(S[0 * P + pid], S[1 * P + pid], S[2 * P + pid]);
+                            dir = mk(S[3 * P + pid], S[4 * P + pid], S[5 * P + pid]);
+                            beta = mk(S[6 * P + pid], S[7 * P + pid], S[8 * P + pid]);
+                        }
+                        st.sp = 0;
+                        trav_begin(a.scene, org, dir, INFINITY, tr);
+                        has_ray = true;
+                    }
+                }
+            }
+            const bool more_to_claim = !drained || c_next != c_end;
+            if (__ballot(has_ray) == 0ull) {
+                if (!more_to_claim) break;
+                continue; // only padding entries were taken: take more
+            }
+            // ---- traverse while enough lanes are busy (all the way once nothing is left to take).  Every step the wave
+            // runs the one phase -- inner-node test or primitive test -- that most of its busy lanes are waiting for,
+            // so each step executes with at least half of the busy lanes.
+            const int keep_going = more_to_claim ? REFILL_BELOW : 1;
+            for (;;) {
+                const bool busy = has_ray && tr.cur != RT_EMPTY;
+                const bool at_leaf = busy && (tr.cur & RT_LEAF) != 0u;
+                const bool at_node = busy && !at_leaf;
+                const int n_node = (int)__popcll(__ballot(at_node));
+                const int n_leaf = (int)__popcll(__ballot(at_leaf));
+                if (n_node + n_leaf < keep_going) break;
+                if (n_node >= n_leaf) {
+                    if (at_node) {
+                        if (count_visits) ++nodes;
+                        trav_node_step(a.scene, RT_TNEAR, tr, st);
+                    }
+                } else {
+                    if (at_leaf) {
+                        if (count_visits) ++tests;
+                        trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
+                    }
+                }
+            }
         }
     }
     if (count_visits) {
@@ -217,8 +276,7 @@ __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t de
 
 // RaySeries::add_sample (crates/rt/src/renderer.rs:63-82, crates/rt/src/math/stat.rs:24-28,165-168) for the `samples`
 // samples of each pixel, in sample order, filter weight 1 (crates/rt/src/filter.rs:30).
-__global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *__restrict__ accum, uint32_t samples,
-                                                           float count_inc) {
+__global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *__restrict__ accum, float count_inc) {
     const size_t P = a.n_paths;
     const size_t N = a.n_pixels;
     const float *__restrict__ S = a.state;
@@ -226,8 +284,9 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *
         float acc[ACCUM_PLANES];
 #pragma unroll
         for (int k = 0; k < ACCUM_PLANES; ++k) acc[k] = accum[(size_t)k * N + i];
-        for (uint32_t s = 0; s < samples; ++s) {
-            const size_t pid = (size_t)s * N + i;
+        const size_t block_base = (i / PIXEL_BLOCK) * (size_t)a.samples * PIXEL_BLOCK + i % PIXEL_BLOCK;
+        for (uint32_t s = 0; s < a.samples; ++s) {
+            const size_t pid = block_base + (size_t)s * PIXEL_BLOCK;
             const float w = 1.0f;
             const float col[3] = {S[9 * P + pid], S[10 * P + pid], S[11 * P + pid]};
 #pragma unroll
@@ -324,10 +383,10 @@ int launch_bounce(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, 
     return check_launch();
 }
 
-int launch_accumulate(const RenderArgs &args, float *d_accum, uint32_t samples, float count_inc, void *stream) {
+int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     const uint32_t grid = blocks_for(args.n_pixels, 256u * 16u);
-    hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(BLOCK), 0, s, args, d_accum, samples, count_inc);
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(BLOCK), 0, s, args, d_accum, count_inc);
     return check_launch();
 }
 

@@ -549,12 +549,13 @@ RT_DEV float safe_rcp(float d) { return 1.0f / (fabsf(d) > 1e-20f ? d : copysign
 // candidate so far.  The stack is separate (`Stack` offers push(uint32_t) / pop() / empty()); the tree's worst-case
 // stack need is known at commit time and the kernels provide that much room.
 struct Trav {
-    float ix, iy, iz;
+    float ix, iy, iz;    // safe reciprocals of the direction
+    float nox, noy, noz; // -origin * reciprocal, so that a slab distance is one fma
     uint32_t cur;
     Closest best;
 };
 
-RT_DEV void trav_begin(const SceneView &sv, V3 d, float tfar, Trav &tr) {
+RT_DEV void trav_begin(const SceneView &sv, V3 o, V3 d, float tfar, Trav &tr) {
     tr.best.t = tfar;
     tr.best.gidx = RT_EMPTY;
     tr.best.slot = 0;
@@ -563,45 +564,41 @@ RT_DEV void trav_begin(const SceneView &sv, V3 d, float tfar, Trav &tr) {
     tr.ix = safe_rcp(d.x);
     tr.iy = safe_rcp(d.y);
     tr.iz = safe_rcp(d.z);
+    tr.nox = -(o.x * tr.ix);
+    tr.noy = -(o.y * tr.iy);
+    tr.noz = -(o.z * tr.iz);
     tr.cur = sv.n_nodes == 0 ? RT_EMPTY : 0u; // root
 }
 
-// One round of traversal: descend through inner nodes until this lane holds a leaf (or is finished), then work through
-// leaves until it holds an inner node again.  Run by all lanes of a wave together, the two phases keep the lanes on
-// the same code.  Visit counters (may be null) count node and primitive fetches.
+// One inner-node step (tr.cur must be an inner node): slab-test the four child boxes, continue with the nearest one
+// hit and push the others, far to near; with no child hit, pop.  The slab test only has to be conservative (boxes are
+// padded at build time), so it uses fused multiply-adds; it never decides a hit.
 template <class Stack>
-RT_DEV void trav_round(const SceneView &sv, V3 o, V3 d, float tnear, Trav &tr, Stack &st, uint32_t *node_visits,
-                       uint32_t *prim_tests) {
-    const float ix = tr.ix, iy = tr.iy, iz = tr.iz;
-    Closest &best = tr.best;
-    uint32_t cur = tr.cur;
-    {
-        // RT_EMPTY carries the leaf bit, so a finished lane falls through both loops
-        while (!(cur & RT_LEAF)) {
-            const F4 *n = sv.nodes + (size_t)cur * RT_NODE_F4;
-            F4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5];
-            F4 cf = n[6];
-            if (node_visits) ++*node_visits;
-            const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, lys[4] = {ly.x, ly.y, ly.z, ly.w};
-            const float lzs[4] = {lz.x, lz.y, lz.z, lz.w}, hxs[4] = {hx.x, hx.y, hx.z, hx.w};
-            const float hys[4] = {hy.x, hy.y, hy.z, hy.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
-            const uint32_t ch[4] = {__builtin_bit_cast(uint32_t, cf.x), __builtin_bit_cast(uint32_t, cf.y),
-                                    __builtin_bit_cast(uint32_t, cf.z), __builtin_bit_cast(uint32_t, cf.w)};
-            float tn[4];
+RT_DEV void trav_node_step(const SceneView &sv, float tnear, Trav &tr, Stack &st) {
+    const F4 *n = sv.nodes + (size_t)tr.cur * RT_NODE_F4;
+    const F4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5];
+    const F4 cf = n[6];
+    const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, lys[4] = {ly.x, ly.y, ly.z, ly.w};
+    const float lzs[4] = {lz.x, lz.y, lz.z, lz.w}, hxs[4] = {hx.x, hx.y, hx.z, hx.w};
+    const float hys[4] = {hy.x, hy.y, hy.z, hy.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
+    const uint32_t ch[4] = {__builtin_bit_cast(uint32_t, cf.x), __builtin_bit_cast(uint32_t, cf.y),
+                            __builtin_bit_cast(uint32_t, cf.z), __builtin_bit_cast(uint32_t, cf.w)};
+    const float tfar = tr.best.t;
+    float tn[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float t0x = (lxs[k] - o.x) * ix, t1x = (hxs[k] - o.x) * ix;
-                float t0y = (lys[k] - o.y) * iy, t1y = (hys[k] - o.y) * iy;
-                float t0z = (lzs[k] - o.z) * iz, t1z = (hzs[k] - o.z) * iz;
-                float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tnear));
-                float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
-                bool hit = (ch[k] != RT_EMPTY) && (tmin <= tmax * 1.0000004f);
-                tn[k] = hit ? tmin : INFINITY;
-            }
-            // 4-element sorting network on (entry distance, child), nearest first; misses carry +inf and RT_EMPTY
-            float a0 = tn[0], a1 = tn[1], a2 = tn[2], a3 = tn[3];
-            uint32_t i0 = a0 < INFINITY ? ch[0] : RT_EMPTY, i1 = a1 < INFINITY ? ch[1] : RT_EMPTY;
-            uint32_t i2 = a2 < INFINITY ? ch[2] : RT_EMPTY, i3 = a3 < INFINITY ? ch[3] : RT_EMPTY;
+    for (int k = 0; k < 4; ++k) {
+        const float t0x = __builtin_fmaf(lxs[k], tr.ix, tr.nox), t1x = __builtin_fmaf(hxs[k], tr.ix, tr.nox);
+        const float t0y = __builtin_fmaf(lys[k], tr.iy, tr.noy), t1y = __builtin_fmaf(hys[k], tr.iy, tr.noy);
+        const float t0z = __builtin_fmaf(lzs[k], tr.iz, tr.noz), t1z = __builtin_fmaf(hzs[k], tr.iz, tr.noz);
+        const float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tnear));
+        const float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tfar));
+        const bool hit = (ch[k] != RT_EMPTY) && (tmin <= tmax * 1.0000004f);
+        tn[k] = hit ? tmin : INFINITY;
+    }
+    // 4-element sorting network on (entry distance, child), nearest first; misses carry +inf and RT_EMPTY
+    float a0 = tn[0], a1 = tn[1], a2 = tn[2], a3 = tn[3];
+    uint32_t i0 = a0 < INFINITY ? ch[0] : RT_EMPTY, i1 = a1 < INFINITY ? ch[1] : RT_EMPTY;
+    uint32_t i2 = a2 < INFINITY ? ch[2] : RT_EMPTY, i3 = a3 < INFINITY ? ch[3] : RT_EMPTY;
 #define RT_CSWAP(ta, ia, tb, ib)          \
     {                                     \
         bool sw = tb < ta;                \
@@ -614,41 +611,51 @@ RT_DEV void trav_round(const SceneView &sv, V3 o, V3 d, float tnear, Trav &tr, S
         ia = ilo;                         \
         ib = ihi;                         \
     }
-            RT_CSWAP(a0, i0, a1, i1)
-            RT_CSWAP(a2, i2, a3, i3)
-            RT_CSWAP(a0, i0, a2, i2)
-            RT_CSWAP(a1, i1, a3, i3)
-            RT_CSWAP(a1, i1, a2, i2)
+    RT_CSWAP(a0, i0, a1, i1)
+    RT_CSWAP(a2, i2, a3, i3)
+    RT_CSWAP(a0, i0, a2, i2)
+    RT_CSWAP(a1, i1, a3, i3)
+    RT_CSWAP(a1, i1, a2, i2)
 #undef RT_CSWAP
-            if (i0 == RT_EMPTY) {
-                cur = st.empty() ? RT_EMPTY : st.pop();
-            } else {
-                if (i3 != RT_EMPTY) st.push(i3);
-                if (i2 != RT_EMPTY) st.push(i2);
-                if (i1 != RT_EMPTY) st.push(i1);
-                cur = i0;
-            }
-        }
-        while (cur != RT_EMPTY && (cur & RT_LEAF)) {
-            uint32_t first = cur & 0x0FFFFFFFu;
-            uint32_t count = ((cur >> 28) & 7u) + 1u;
-            for (uint32_t k = 0; k < count; ++k) {
-                if (prim_tests) ++*prim_tests;
-                test_prim(sv, first + k, o, d, tnear, best);
-            }
-            cur = st.empty() ? RT_EMPTY : st.pop();
-        }
+    if (i0 == RT_EMPTY) {
+        tr.cur = st.empty() ? RT_EMPTY : st.pop();
+    } else {
+        if (i3 != RT_EMPTY) st.push(i3);
+        if (i2 != RT_EMPTY) st.push(i2);
+        if (i1 != RT_EMPTY) st.push(i1);
+        tr.cur = i0;
     }
-    tr.cur = cur;
 }
 
-// Closest hit of o + t d over (tnear, tfar] in the 4-wide BVH.
+// One leaf step (tr.cur must be a leaf reference other than RT_EMPTY): test the leaf's first primitive, then continue
+// with the rest of the leaf or pop.
+template <class Stack>
+RT_DEV void trav_leaf_step(const SceneView &sv, V3 o, V3 d, float tnear, Trav &tr, Stack &st) {
+    const uint32_t first = tr.cur & 0x0FFFFFFFu;
+    const uint32_t more = (tr.cur >> 28) & 7u; // primitives after this one
+    test_prim(sv, first, o, d, tnear, tr.best);
+    if (more != 0u)
+        tr.cur = RT_LEAF | ((more - 1u) << 28) | (first + 1u);
+    else
+        tr.cur = st.empty() ? RT_EMPTY : st.pop();
+}
+
+// Closest hit of o + t d over (tnear, tfar] in the 4-wide BVH, one lane on its own.  Visit counters (may be null) count
+// node and primitive fetches.
 template <class Stack>
 RT_DEV void closest_hit(const SceneView &sv, V3 o, V3 d, float tnear, float tfar, Stack &st, Closest &best,
                         uint32_t *node_visits, uint32_t *prim_tests) {
     Trav tr;
-    trav_begin(sv, d, tfar, tr);
-    while (tr.cur != RT_EMPTY) trav_round(sv, o, d, tnear, tr, st, node_visits, prim_tests);
+    trav_begin(sv, o, d, tfar, tr);
+    while (tr.cur != RT_EMPTY) {
+        if (!(tr.cur & RT_LEAF)) {
+            if (node_visits) ++*node_visits;
+            trav_node_step(sv, tnear, tr, st);
+        } else {
+            if (prim_tests) ++*prim_tests;
+            trav_leaf_step(sv, o, d, tnear, tr, st);
+        }
+    }
     best = tr.best;
 }
 

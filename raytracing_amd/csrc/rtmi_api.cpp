@@ -538,11 +538,18 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         spp_pass = (uint32_t)std::max<size_t>(1, target_paths / npix);
     }
     spp_pass = std::min(spp_pass, n_samples);
-    if ((size_t)spp_pass * npix >= (1ull << 31)) spp_pass = (uint32_t)std::max<size_t>(1, ((1ull << 31) - 1) / npix);
-    const size_t max_paths = (size_t)spp_pass * npix;
+    // path ids are laid out per 64-pixel block (see kernels.h): pad the pixel count to whole blocks
+    const size_t n_blocks = (npix + rtk::PIXEL_BLOCK - 1) / rtk::PIXEL_BLOCK;
+    const size_t padded_pix = n_blocks * rtk::PIXEL_BLOCK;
+    const size_t seg_blocks = (n_blocks + rtk::SEGMENTS - 1) / rtk::SEGMENTS;
+    const size_t queue_pix = seg_blocks * rtk::SEGMENTS * rtk::PIXEL_BLOCK; // per sample, all segments
+    if ((size_t)spp_pass * queue_pix >= (1ull << 31))
+        spp_pass = (uint32_t)std::max<size_t>(1, ((1ull << 31) - 1) / queue_pix);
+    const size_t max_paths = (size_t)spp_pass * queue_pix;
     const uint32_t n_passes = (n_samples + spp_pass - 1) / spp_pass;
-    const size_t per_pass = (size_t)params->max_depth + 2;
-    const size_t n_counters = per_pass * n_passes;
+    // counters of one pass (reused by the next): SEGMENTS per bounce, each on its own 256-byte line
+    const size_t per_bounce = (size_t)rtk::SEGMENTS * rtk::COUNTER_STRIDE;
+    const size_t n_counters = ((size_t)params->max_depth + 2) * per_bounce;
 
     if (film->cap_paths < max_paths) {
         if (film->d_state) (void)hipFree(film->d_state);
@@ -565,7 +572,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     }
     uint32_t *d_counts = film->d_counts;
     uint32_t *d_work = film->d_counts + film->cap_counters;
-    HIP_TRY(hipMemsetAsync(film->d_counts, 0, 2 * film->cap_counters * sizeof(uint32_t), stream));
+    std::vector<uint32_t> h_counts(per_bounce);
 
     rtk::RenderArgs a{};
     a.scene = scene->view;
@@ -583,6 +590,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.queue[1] = film->d_queue[1];
     a.visit_counters = dev->count_visits ? dev->d_visits : nullptr;
     a.n_pixels = (uint32_t)npix;
+    a.n_blocks = (uint32_t)n_blocks;
     a.strata = (uint32_t)floorf(sqrtf((float)params->spp)); // executor.rs:218
     if (a.strata == 0) a.strata = 1;
     a.max_depth = params->max_depth;
@@ -600,22 +608,54 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     HIP_TRY(hipEventRecord(ev_begin, stream));
     int rc = RTMI_OK;
     uint32_t sample = params->sample_begin;
+    uint64_t rays = 0, paths = 0;
+    uint32_t deepest = 0, launches = 0;
+    const uint32_t waves_per_block = rtk::BLOCK / 64;
     for (uint32_t pass = 0; pass < n_passes && rc == RTMI_OK; ++pass) {
         const uint32_t k = std::min(spp_pass, params->sample_end - sample);
-        a.n_paths = (uint32_t)((size_t)k * npix);
+        a.samples = k;
+        a.n_paths = (uint32_t)((size_t)k * padded_pix);
+        a.seg_cap = (uint32_t)(seg_blocks * rtk::PIXEL_BLOCK * k);
         a.sample_base = sample;
-        a.counts = d_counts + (size_t)pass * per_pass;
-        a.work = d_work + (size_t)pass * per_pass;
-        const uint32_t grid = std::min<uint32_t>(full_grid, (a.n_paths + rtk::BLOCK - 1) / rtk::BLOCK);
+        a.counts = d_counts;
+        a.work = d_work;
+        hipError_t e = hipMemsetAsync(film->d_counts, 0, 2 * film->cap_counters * sizeof(uint32_t), stream);
+        if (e != hipSuccess) {
+            rc = fail(RTMI_ERR_DEVICE, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+            break;
+        }
         (void)hipEventRecord(ev_pass[2 * pass], stream);
-        for (uint32_t depth = 0; depth < params->max_depth; ++depth) {
+        uint64_t live = (uint64_t)k * npix; // rays entering the bounce about to be launched
+        paths += live;
+        for (uint32_t depth = 0; depth < params->max_depth && live > 0; ++depth) {
+            rays += live;
+            if (depth > deepest) deepest = depth;
+            // grid sized to the work: one wave per 64 queue entries, capped at the resident grid; a wave claims
+            // several batches per atomic when the queue is long
+            const uint64_t entries = depth == 0 ? (uint64_t)a.n_paths : live;
+            const uint64_t want_blocks = (entries + 64 * waves_per_block - 1) / (64 * waves_per_block);
+            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full_grid, want_blocks));
+            const uint64_t per_wave = entries / ((uint64_t)grid * waves_per_block * rtk::SEGMENTS) / 8;
+            a.claim = 64u * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, per_wave / 64));
             if (rtk::launch_bounce(a, depth, grid, stream)) {
                 rc = fail(RTMI_ERR_DEVICE, "bounce kernel launch failed");
                 break;
             }
+            ++launches;
+            if (depth + 1 == params->max_depth) break;
+            // the survivors' count sizes (or ends) the next launch
+            e = hipMemcpyAsync(h_counts.data(), d_counts + (size_t)(depth + 1) * per_bounce,
+                               per_bounce * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+                break;
+            }
+            live = 0;
+            for (int x = 0; x < rtk::SEGMENTS; ++x) live += h_counts[(size_t)x * rtk::COUNTER_STRIDE];
         }
         (void)hipEventRecord(ev_pass[2 * pass + 1], stream);
-        if (rc == RTMI_OK && rtk::launch_accumulate(a, film->d_accum, k, 1.0f, stream))
+        if (rc == RTMI_OK && rtk::launch_accumulate(a, film->d_accum, 1.0f, stream))
             rc = fail(RTMI_ERR_DEVICE, "accumulate kernel launch failed");
         sample += k;
     }
@@ -623,25 +663,16 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     hipError_t e = hipStreamSynchronize(stream);
     if (rc == RTMI_OK && e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
     if (rc == RTMI_OK && stats) {
-        std::vector<uint32_t> counts(n_counters);
-        e = hipMemcpy(counts.data(), d_counts, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("counter readback: ") + hipGetErrorString(e));
-        uint32_t s2 = params->sample_begin;
+        stats->rays = rays;
+        stats->paths = paths;
+        stats->max_bounces = deepest;
+        stats->passes = n_passes;
+        stats->bounce_launches = launches;
         for (uint32_t pass = 0; pass < n_passes; ++pass) {
-            const uint32_t k = std::min(spp_pass, params->sample_end - s2);
-            s2 += k;
-            stats->paths += (uint64_t)k * npix;
-            stats->rays += (uint64_t)k * npix;
-            for (uint32_t d = 1; d < params->max_depth; ++d) {
-                const uint32_t c = counts[(size_t)pass * per_pass + d];
-                stats->rays += c;
-                if (c && d > stats->max_bounces) stats->max_bounces = d;
-            }
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, ev_pass[2 * pass], ev_pass[2 * pass + 1]) == hipSuccess)
                 stats->bounce_ms += ms;
         }
-        stats->passes = n_passes;
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->gpu_ms = ms;
     }

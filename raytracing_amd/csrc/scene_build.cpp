@@ -26,11 +26,13 @@ void prim_box(const HostPrim &p, rtb::Box &b) {
     }
 }
 
-// Culling boxes are padded so that a hit the f32 primitive test accepts is never culled by the slab test.
-void pad_box(rtb::Box &b) {
+// Culling boxes are padded so that a hit the f32 primitive test accepts is never culled by the slab test, whose
+// distances are fused multiply-adds of magnitudes up to |origin| / |direction component|: a term relative to the box's
+// own coordinates plus one relative to the scene's (covering ray origins within ~16 scene extents).
+void pad_box(rtb::Box &b, float scene_scale) {
     float m = 0.0f;
     for (int k = 0; k < 3; ++k) m = fmaxf(m, fmaxf(fabsf(b.lo[k]), fabsf(b.hi[k])));
-    const float e = 1e-5f * m + 1e-30f;
+    const float e = 1e-5f * m + 1e-6f * scene_scale + 1e-30f;
     for (int k = 0; k < 3; ++k) {
         b.lo[k] -= e;
         b.hi[k] += e;
@@ -70,8 +72,11 @@ bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, std::vec
             lo[k] = fminf(lo[k], boxes[i].lo[k]);
             hi[k] = fmaxf(hi[k], boxes[i].hi[k]);
         }
-        pad_box(boxes[i]);
     }
+    float scene_scale = 0.0f;
+    for (int k = 0; k < 3; ++k)
+        if (n) scene_scale = fmaxf(scene_scale, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+    for (size_t i = 0; i < n; ++i) pad_box(boxes[i], scene_scale);
     if (!rtb::build(boxes, bvh, progress)) return false;
     records.assign(n * rtd::RT_PRIM_F4, rtd::F4{0.0f, 0.0f, 0.0f, 0.0f});
     for (size_t slot = 0; slot < n; ++slot) {
