@@ -60,6 +60,8 @@ struct RenderArgs {
     uint32_t seg_cap;     // queue entries per segment
     uint32_t n_paths;     // n_blocks * PIXEL_BLOCK * samples
     uint32_t claim;       // queue entries a wave claims with one atomic (a multiple of 64)
+    int32_t refill_below; // a wave stops traversing to shade and refill when fewer lanes than this are busy
+    int32_t leaf_bias;    // a primitive-test step is run when leaf lanes + bias > node lanes
     uint32_t sample_base; // first sample index of the pass
     uint32_t strata;      // floor(sqrt(spp))
     uint32_t max_depth;

@@ -83,9 +83,8 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const
 
 // Lanes refill themselves: a lane whose ray has finished traversal shades it, publishes the continuation and takes the
 // next queue entry, while the other lanes of the wave keep their rays.  To keep both halves efficient the wave only
-// leaves the traversal loop when fewer than REFILL_BELOW lanes are still traversing (or the queue is drained and
-// nothing is left), so traversal runs with most lanes busy and shading runs for a batch of lanes at a time.
-constexpr int REFILL_BELOW = 44;
+// leaves the traversal loop when fewer than RenderArgs::refill_below lanes are still traversing (or the queue is
+// drained and nothing is left), so traversal runs with most lanes busy and shading runs for a batch of lanes at a time.
 
 // XCC_ID hardware register (bits 3:0): the XCD this wave runs on.  Used for locality only, never for correctness.
 __device__ __forceinline__ uint32_t xcd_of_wave() {
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t de
             // ---- traverse while enough lanes are busy (all the way once nothing is left to take).  Every step the wave
             // runs the one phase -- inner-node test or primitive test -- that most of its busy lanes are waiting for,
             // so each step executes with at least half of the busy lanes.
-            const int keep_going = more_to_claim ? REFILL_BELOW : 1;
+            const int keep_going = more_to_claim ? a.refill_below : 1;
             for (;;) {
                 const bool busy = has_ray && tr.cur != RT_EMPTY;
                 const bool at_leaf = busy && (tr.cur & RT_LEAF) != 0u;
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t de
                 const int n_node = (int)__popcll(__ballot(at_node));
                 const int n_leaf = (int)__popcll(__ballot(at_leaf));
                 if (n_node + n_leaf < keep_going) break;
-                if (n_node >= n_leaf) {
+                if (n_leaf == 0 || (n_node > 0 && n_node >= n_leaf + a.leaf_bias)) {
                     if (at_node) {
                         if (count_visits) ++nodes;
                         trav_node_step(a.scene, RT_TNEAR, tr, st);

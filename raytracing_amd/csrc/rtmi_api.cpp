@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -597,6 +598,10 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.integrator = params->integrator;
     a.seed = params->seed;
 
+    a.refill_below = 32;
+    a.leaf_bias = 0;
+    if (const char *v = getenv("RTMI_REFILL_BELOW")) a.refill_below = atoi(v);
+    if (const char *v = getenv("RTMI_LEAF_BIAS")) a.leaf_bias = atoi(v);
     a.spill = scene->d_spill;
     const uint32_t full_grid = scene->grid_blocks;
 
