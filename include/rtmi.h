@@ -102,6 +102,10 @@ typedef struct rtmi_render_params {
     uint32_t integrator;   /* RTMI_INTEGRATOR_* */
     uint32_t samples_per_pass; /* samples of every pixel traced together; 0 = library default */
     uint64_t seed;         /* --seed */
+    float allowed_error;   /* --allowed-error (executor.rs:244-249): within one call a pixel stops accumulating once
+                            * the 95 % confidence error of all three colour channels is below this; <= 0 = off.  The
+                            * reference applies it per batch of 32 samples: call once per batch to reproduce that. */
+    uint32_t reserved;
 } rtmi_render_params;
 
 typedef struct rtmi_render_stats {

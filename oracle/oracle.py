@@ -41,7 +41,8 @@ class Camera(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
                 ("max_depth", C.c_uint32), ("integrator", C.c_uint32), ("isect_mode", C.c_uint32),
-                ("form", C.c_uint32), ("threads", C.c_uint32), ("seed", C.c_uint64)]
+                ("form", C.c_uint32), ("threads", C.c_uint32), ("seed", C.c_uint64), ("allowed_error", C.c_float),
+                ("reserved", C.c_uint32)]
 
 
 class Tile(C.Structure):
@@ -144,7 +145,7 @@ def make_camera(cam):
 
 
 def make_params(spp, sample_begin=0, sample_end=None, max_depth=64, integrator=0, isect_mode=ISECT_BVH,
-                form=FORM_ITERATIVE, threads=0, seed=0):
+                form=FORM_ITERATIVE, threads=0, seed=0, allowed_error=0.0):
     p = RenderParams()
     p.spp = spp
     p.sample_begin = sample_begin
@@ -155,6 +156,7 @@ def make_params(spp, sample_begin=0, sample_end=None, max_depth=64, integrator=0
     p.form = form
     p.threads = threads
     p.seed = seed
+    p.allowed_error = allowed_error or 0.0
     return p
 
 

@@ -1145,6 +1145,21 @@ uint32_t orc_render_sample(const orc_scene *s, const orc_camera *cam, const orc_
     return rays;
 }
 
+/* stat.rs:92-95 */
+static const float STUDENT_5[16] = {2.131f, 2.120f, 2.110f, 2.101f, 2.093f, 2.086f, 2.080f, 2.074f,
+                                    2.069f, 2.064f, 2.060f, 2.056f, 2.052f, 2.048f, 2.045f, 2.042f};
+
+static float variance_of(float count, float sum, float sqsum);
+
+/* VarianceSeries::is_precise_enough, stat.rs:57-78 */
+static int channel_precise(float count, float sum, float sqsum, float abs_err) {
+    float df = count - 1.0f;
+    if (df < 15.0f) return 0;
+    int idx = (int)(df < 30.0f ? df : 30.0f) - 15;
+    float err = STUDENT_5[idx] * sqrtf(variance_of(count, sum, sqsum));
+    return err < abs_err;
+}
+
 /* executor.rs:207-252 (tile_worker's per-pixel sample loop) + renderer.rs:63-82 (add_sample, weight 1) */
 uint64_t orc_render(const orc_scene *s, const orc_camera *cam, const orc_render_params *p, const uint32_t *xy,
                     size_t n_pixels, float *accum) {
@@ -1181,6 +1196,11 @@ uint64_t orc_render(const orc_scene *s, const orc_camera *cam, const orc_render_
             a[19] += r.z;
             a[20] += r.ray_depth;
             a[21] += (float)r.samples;
+            /* executor.rs:244-249: stop this pixel for the rest of the batch once all three channels are precise */
+            if (p->allowed_error > 0.0f && channel_precise(a[21], a[0], a[3], p->allowed_error) &&
+                channel_precise(a[21], a[1], a[4], p->allowed_error) &&
+                channel_precise(a[21], a[2], a[5], p->allowed_error))
+                break;
         }
         for (int k = 0; k < ORC_ACCUM_PLANES; ++k) accum[(size_t)k * n_pixels + (size_t)i] = a[k];
     }

@@ -114,6 +114,8 @@ typedef struct {
     uint32_t form;       /* ORC_FORM_* (path tracer only) */
     uint32_t threads;    /* 0 = OpenMP default */
     uint64_t seed;
+    float allowed_error; /* --allowed-error; <= 0 or NaN = off (executor.rs:244-249) */
+    uint32_t reserved;
 } orc_render_params;
 
 /* tile.rs:4-9 */

@@ -330,7 +330,7 @@ class Film:
 
 
 def render(world: CommittedHipScene, film: Film, camera: Camera, spp: int, sample_range=None, max_depth: int = 64,
-           integrator: int = 0, seed: int = 0, samples_per_pass: int = 0):
+           integrator: int = 0, seed: int = 0, samples_per_pass: int = 0, allowed_error: float = 0.0):
     """rtmi_render: adds samples `sample_range` (default 0..spp) of every film pixel.  Returns the stats dict."""
     p = _lib.RenderParams()
     p.spp = int(spp)
@@ -340,6 +340,7 @@ def render(world: CommittedHipScene, film: Film, camera: Camera, spp: int, sampl
     p.integrator = int(integrator)
     p.samples_per_pass = int(samples_per_pass)
     p.seed = int(seed)
+    p.allowed_error = float(allowed_error or 0.0)
     cam = camera_pod(camera)
     st = _lib.RenderStats()
     check(world._l.rtmi_render(world._h, film._h, C.byref(cam), C.byref(p), C.byref(st)))
@@ -367,12 +368,12 @@ class Executor:
                      self.tile_size)
 
     def run_multithreaded(self, world, on_tile_rendered, pixel_range=None, sample_range=None, tiles=None,
-                          batch_size=32):
+                          batch_size=32, srgb=False):
         """Renders `sample_range` of every pixel in `pixel_range` on the GPU and reports each tile to
         `on_tile_rendered(TileMsg)` after every batch of `batch_size` samples (SampleCounter, executor.rs:132,333-370).
-        `tiles` restricts the work to a subset of tile indices (how ranks split a frame)."""
-        if self.allowed_error is not None:
-            raise NotImplementedError("--allowed-error (adaptive sampling) is not offered by the GPU executor yet")
+        `tiles` restricts the work to a subset of tile indices (how ranks split a frame).  `srgb` delivers the four RGB
+        channels sRGB-encoded, as OutputBuffers::convert stores them (crates/rt-cli/src/output/mod.rs:46-51).
+        --allowed-error is applied per batch, as the reference does (executor.rs:132,244-249)."""
         W, H = self.dimension
         pixel_range = pixel_range or RenderRange(range(0, W), range(0, H))
         sample_range = sample_range if sample_range is not None else range(0, self.spp)
@@ -389,13 +390,13 @@ class Executor:
             while cur < sample_range.stop:
                 n = min(batch_size, sample_range.stop - cur) if batch_size else sample_range.stop - cur
                 st = render(world, film, self.camera, self.spp, range(cur, cur + n), self.max_depth,
-                            INTEGRATORS[self.integrator], self.seed)
+                            INTEGRATORS[self.integrator], self.seed, 0, self.allowed_error or 0.0)
                 for k in ("rays", "paths", "passes", "gpu_ms", "bounce_ms", "bounce_launches"):
                     stats[k] += st[k]
                 stats["max_bounces"] = max(stats["max_bounces"], st["max_bounces"])
                 cur += n
                 if on_tile_rendered is not None:
-                    res = film.resolve(srgb=False)
+                    res = film.resolve(srgb=srgb)
                     for t, a, b in zip(tile_list, offsets[:-1], offsets[1:]):
                         on_tile_rendered(TileMsg(t, res[:, a:b].T.copy()))
             self.last_stats = stats

@@ -62,6 +62,7 @@ struct RenderArgs {
     uint32_t claim;       // queue entries a wave claims with one atomic (a multiple of 64)
     int32_t refill_below; // a wave stops traversing to shade and refill when fewer lanes than this are busy
     int32_t leaf_bias;    // a primitive-test step is run when leaf lanes + bias > node lanes
+    float allowed_error;  // > 0: a pixel stops accumulating within this pass once its colour error is below it
     uint32_t sample_base; // first sample index of the pass
     uint32_t strata;      // floor(sqrt(spp))
     uint32_t max_depth;

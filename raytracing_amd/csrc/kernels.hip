@@ -273,6 +273,26 @@ __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t de
     }
 }
 
+// crates/rt/src/math/stat.rs:45-52
+__device__ __forceinline__ float variance_of(float count, float sum, float sqsum) {
+    if (count <= 2.0f) return INFINITY;
+    return (sqsum - sum * sum / count) / (count - 1.0f);
+}
+
+// VarianceSeries::is_precise_enough (crates/rt/src/math/stat.rs:57-78) with the Student table of stat.rs:92-95
+__device__ __forceinline__ bool channel_precise(float count, float sum, float sqsum, float abs_err) {
+    const float student[16] = {2.131f, 2.120f, 2.110f, 2.101f, 2.093f, 2.086f, 2.080f, 2.074f,
+                               2.069f, 2.064f, 2.060f, 2.056f, 2.052f, 2.048f, 2.045f, 2.042f};
+    const float df = count - 1.0f;
+    if (df < 15.0f) return false;
+    const int idx = (int)(df < 30.0f ? df : 30.0f) - 15;
+    float t = student[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t = (idx == k) ? student[k] : t;
+    const float err = t * sqrtf(variance_of(count, sum, sqsum));
+    return err < abs_err;
+}
+
 // RaySeries::add_sample (crates/rt/src/renderer.rs:63-82, crates/rt/src/math/stat.rs:24-28,165-168) for the `samples`
 // samples of each pixel, in sample order, filter weight 1 (crates/rt/src/filter.rs:30).
 __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *__restrict__ accum, float count_inc) {
@@ -300,6 +320,11 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *
             acc[19] += S[21 * P + pid];
             acc[20] += S[22 * P + pid];
             acc[21] += count_inc;
+            // crates/rt-cli/src/executor.rs:244-249: the pixel is done for this batch once all channels are precise
+            if (a.allowed_error > 0.0f && channel_precise(acc[21], acc[0], acc[3], a.allowed_error) &&
+                channel_precise(acc[21], acc[1], acc[4], a.allowed_error) &&
+                channel_precise(acc[21], acc[2], acc[5], a.allowed_error))
+                break;
         }
 #pragma unroll
         for (int k = 0; k < ACCUM_PLANES; ++k) accum[(size_t)k * N + i] = acc[k];
@@ -312,12 +337,6 @@ __device__ __forceinline__ float srgb_from_linear(float linear) {
     linear = linear < 0.0f ? 0.0f : (linear > 1.0f ? 1.0f : linear);
     if (linear < 0.0031308f) return 12.92f * linear;
     return 1.055f * powf(linear, 1.0f / 2.4f) - 0.055f;
-}
-
-// crates/rt/src/math/stat.rs:45-52
-__device__ __forceinline__ float variance_of(float count, float sum, float sqsum) {
-    if (count <= 2.0f) return INFINITY;
-    return (sqsum - sum * sum / count) / (count - 1.0f);
 }
 
 // RaySeries::as_pixelresult (crates/rt/src/renderer.rs:37-61) [+ OutputBuffers::convert, output/mod.rs:46-58]

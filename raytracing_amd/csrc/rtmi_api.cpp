@@ -598,6 +598,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.integrator = params->integrator;
     a.seed = params->seed;
 
+    a.allowed_error = (params->allowed_error > 0.0f) ? params->allowed_error : 0.0f;
     a.refill_below = 32;
     a.leaf_bias = 0;
     if (const char *v = getenv("RTMI_REFILL_BELOW")) a.refill_below = atoi(v);

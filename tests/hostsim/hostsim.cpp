@@ -51,6 +51,8 @@ struct Hit {
 struct Params {
     uint32_t spp, sample_begin, sample_end, max_depth, integrator, samples_per_pass;
     uint64_t seed;
+    float allowed_error;
+    uint32_t reserved;
 };
 
 } // namespace

@@ -331,3 +331,50 @@ def test_deep_traversal_stack_spills(oracle, device):
     rays["tnear"] = 1e-5
     rays["tfar"] = np.inf
     check_hits(world.intersect(rays), so.intersect(rays, oracle.ISECT_BRUTE))
+
+
+def test_allowed_error_adaptive_sampling(oracle, scene_classes, device):
+    """--allowed-error: within a batch a pixel stops accumulating once all three channels are precise
+    (executor.rs:244-249); batches of 32 as the reference's SampleCounter.  Sky pixels (zero variance) stop at 16
+    samples, then take one sample per later batch."""
+    from raytracing_amd import api, types
+    so, world = build_pair(oracle, scene_classes["debug"], device)
+    W, H, spp = 96, 54, 70
+    cam = types.Camera.from_dimensions(W, H)
+    xy = full_frame_xy(W, H)
+    want = None
+    film = api.Film(device, xy)
+    for a, b in ((0, 32), (32, 64), (64, 70)):
+        p = oracle.make_params(spp=spp, sample_begin=a, sample_end=b, allowed_error=0.05)
+        want, _ = so.render(cam, p, xy, want)
+        api.render(world, film, cam, spp, range(a, b), allowed_error=0.05)
+    got = film.download()
+    film.close()
+    assert same_bits(got, want).all()
+    counts = got[21]
+    assert counts.min() == 16 + 1 + 1 and counts.max() > 18  # sky: 16, then one per later batch
+    # the executor applies it per batch of 32 by itself
+    ex = api.Executor((W, H), spp=spp, camera=cam, allowed_error=0.05)
+    ex.run_multithreaded(world, None)
+    order = np.argsort(ex.last_xy[:, 1].astype(np.int64) * W + ex.last_xy[:, 0])
+    assert same_bits(ex.last_accum[:, order], want).all()
+
+
+def test_cli_writes_the_reference_outputs(device, tmp_path):
+    """`rt-cli --scene debug --spp 4 -d 64x36 -o file`: seven channels, LDR JPEG + HDR files, RGB channels sRGB-encoded
+    (output/mod.rs:46-51), sky colour (186, 149, 254) as in the reference's renders."""
+    from PIL import Image
+    from raytracing_amd import cli
+    assert cli.main(["--scene", "debug", "--spp", "4", "-d", "64x36", "-o", "file", "--outdir", str(tmp_path),
+                     "--seed", "3", "-r", "0..64x0..36"]) == 0
+    names = ["Normal", "Position", "Albedo", "Color", "Variance", "Z", "RayDepth"]
+    for n in names:
+        assert (tmp_path / "ldr" / (n + ".jpeg")).exists() and (tmp_path / "hdr" / (n + ".pfm")).exists()
+    color = np.load(tmp_path / "hdr" / "Color.npy")
+    assert color.shape == (36, 64, 3)
+    corner = np.round(color[0, 0] * 255)
+    assert tuple(corner) == (188.0, 149.0, 255.0) or np.allclose(corner, (188, 149, 255), atol=2)
+    jpg = np.asarray(Image.open(tmp_path / "ldr" / "Color.jpeg"))
+    assert jpg.shape == (36, 64, 3) and abs(int(jpg[0, 0, 2]) - 255) <= 3
+    z = np.load(tmp_path / "hdr" / "Z.npy")
+    assert z.shape == (36, 64) and z.max() > 0.5 and z[0, 0] == 0.0
