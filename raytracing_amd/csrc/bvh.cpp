@@ -1,4 +1,5 @@
-// bvh.cpp -- binned-SAH BVH2 build (multi-threaded over subtrees), collapse to BVH4, breadth-first flatten.
+// bvh.cpp -- binned-SAH BVH2 build (multi-threaded over subtrees), collapse to BVH4, breadth-first flatten into
+// 64-byte nodes with 8-bit child boxes.
 #include "bvh.h"
 
 #include <math.h>
@@ -13,7 +14,8 @@ namespace rtb {
 namespace {
 
 constexpr int BINS = 16;
-constexpr uint32_t LEAF_MAX = 4;
+constexpr uint32_t LEAF_MAX = 1; // items per leaf; the scene builder passes primitive records of up to two triangles; measured on a
+                                 // 5 M-triangle mesh, one record per leaf is 6 % faster than two
 constexpr uint32_t PARALLEL_MIN = 32768; // subtrees at least this large may get their own thread
 
 struct Node2 {
@@ -247,15 +249,42 @@ bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool
                 ++nc;
             }
         }
-        rtd::F4 slots[rtd::RT_NODE_F4];
-        float *f = reinterpret_cast<float *>(slots);
+        // Quantisation frame of this node: origin = low corner of the union of its child boxes, one power-of-two step
+        // per axis such that 255 steps span the union.  Child planes are rounded outwards, so a decoded box always
+        // contains the box it stands for.
+        Box u;
+        box_init(u);
+        for (int k = 0; k < nc; ++k) box_grow(u, N2[ch[k]].box);
+        float org[3], step[3];
+        for (int a = 0; a < 3; ++a) {
+            org[a] = isfinite(u.lo[a]) ? u.lo[a] : 0.0f;
+            const double ext = (double)u.hi[a] - (double)org[a];
+            int e = -100;
+            if (!(ext <= 1e30)) // non-finite or huge
+                e = 100;
+            else if (ext > 0.0) {
+                e = (int)ceil(log2(ext / 255.0));
+                if (ldexp(255.0, e) < ext) ++e;
+                if (e < -100) e = -100;
+            }
+            step[a] = (float)ldexp(1.0, e);
+        }
+        uint32_t qw[6] = {0, 0, 0, 0, 0, 0}; // lo.x, lo.y, lo.z, hi.x, hi.y, hi.z; child k in byte k
         uint32_t refs[4];
         for (int k = 0; k < 4; ++k) {
             if (k < nc) {
                 const Node2 &c = N2[ch[k]];
                 for (int a = 0; a < 3; ++a) {
-                    f[4 * a + k] = c.box.lo[a];
-                    f[4 * (3 + a) + k] = c.box.hi[a];
+                    const double o = org[a], st = step[a];
+                    double ql = floor(((double)c.box.lo[a] - o) / st), qh = ceil(((double)c.box.hi[a] - o) / st);
+                    if (!(ql >= 0.0)) ql = 0.0;
+                    if (!(qh <= 255.0)) qh = 255.0;
+                    if (!(ql <= 255.0)) ql = 255.0;
+                    if (!(qh >= 0.0)) qh = 0.0;
+                    while (ql > 0.0 && o + ql * st > (double)c.box.lo[a]) ql -= 1.0;
+                    while (qh < 255.0 && o + qh * st < (double)c.box.hi[a]) qh += 1.0;
+                    qw[a] |= (uint32_t)ql << (8 * k);
+                    qw[3 + a] |= (uint32_t)qh << (8 * k);
                 }
                 if (c.count > 0) {
                     refs[k] = rtd::RT_LEAF | ((c.count - 1u) << 28) | c.first;
@@ -266,15 +295,19 @@ bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool
                     if (root_area > 0.0f) sah += (double)half_area(c.box) / root_area;
                 }
             } else {
-                for (int a = 0; a < 3; ++a) {
-                    f[4 * a + k] = INFINITY;
-                    f[4 * (3 + a) + k] = -INFINITY;
-                }
                 refs[k] = rtd::RT_EMPTY;
             }
         }
-        memcpy(&f[24], refs, sizeof refs);
-        for (int k = 28; k < 32; ++k) f[k] = 0.0f;
+        rtd::F4 slots[rtd::RT_NODE_F4];
+        float *f = reinterpret_cast<float *>(slots);
+        f[0] = org[0];
+        f[1] = org[1];
+        f[2] = org[2];
+        f[3] = step[0];
+        f[4] = step[1];
+        f[5] = step[2];
+        memcpy(&f[6], qw, sizeof qw);
+        memcpy(&f[12], refs, sizeof refs);
         for (int k = 0; k < rtd::RT_NODE_F4; ++k) W.push_back(slots[k]);
         nchild.push_back((uint8_t)nc);
         for (int k = 0; k < 4; ++k) child_ref.push_back(refs[k]);

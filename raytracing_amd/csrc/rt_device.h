@@ -30,7 +30,8 @@ namespace rtd {
 
 // ---------------------------------------------------------------------------------------------- layout
 
-// 128-byte BVH4 node: child boxes SoA (lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4]), child refs, padding.
+// 64-byte BVH4 node, 16 words: origin.xyz, step.xyz (f32), six words of 8-bit child planes (lo.x, lo.y, lo.z, hi.x,
+// hi.y, hi.z; child k in byte k; plane = origin + q * step, rounded outwards at build time), four child refs.
 // Child ref: RT_EMPTY = unused slot; bit 31 set = leaf: bits 28..30 = prim count - 1, bits 0..27 = first prim slot;
 // otherwise the index of an inner node.
 struct alignas(16) F4 {
@@ -42,11 +43,16 @@ struct alignas(16) U4 {
 constexpr uint32_t RT_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t RT_LEAF = 0x80000000u;
 constexpr uint32_t RT_SPHERE = 0x80000000u;
-constexpr int RT_NODE_F4 = 8; // float4s per node
-constexpr int RT_PRIM_F4 = 3; // float4s per primitive
+constexpr int RT_NODE_F4 = 4; // float4s per node
+constexpr uint32_t RT_GEOM_MASK = 0x00FFFFFFu;
+constexpr int RT_PRIM_F4 = 4; // float4s per primitive record
 
-// 48-byte primitive: triangle = v0.xyz, e1.xyz (v1 - v0), e2.xyz (v2 - v0); sphere = centre.xyz, radius.
-// Words 9..11: global primitive index (insertion order), geometry id | RT_SPHERE, primitive id inside the geometry.
+// 64-byte primitive record, 16 words: four points a, b, c, d (12 words), then the global primitive index (insertion
+// order) of the first and of the second triangle (RT_EMPTY = none), geometry id | selectors << 24 | RT_SPHERE, and the
+// global index of the geometry's first primitive.  The first triangle is (a, b, c) in its own vertex order; the second
+// shares two corners with it and names its corners by three 2-bit selectors into (a, b, c, d), again in its own
+// order, so that both are tested on exactly the edge vectors v1 - v0, v2 - v0 of the triangle as it was inserted.
+// A sphere keeps its centre in a and its radius in b.x.
 
 struct Material {
     uint32_t kind;
@@ -476,35 +482,82 @@ RT_DEV void camera_ray(const CameraView &cam, uint32_t strata, uint64_t seed, ui
 struct Closest {
     float t;
     uint32_t gidx; // global primitive index of the best candidate, RT_EMPTY = none
-    uint32_t slot; // its slot in the primitive array
+    uint32_t slot; // 2 * its record slot + its place in the record
     float u, v;
     V3 ng; // spheres only
 };
 
 // Candidate order: smaller t wins, equal t goes to the smaller global primitive index, so the result is the same
 // for every traversal order.
+RT_DEV void take_candidate(float t, uint32_t gidx, uint32_t slot, float u, float v, V3 ng, bool ok, Closest &best) {
+    if (ok && (t < best.t || (t == best.t && gidx < best.gidx))) {
+        best.t = t;
+        best.gidx = gidx;
+        best.slot = slot;
+        best.u = u;
+        best.v = v;
+        best.ng = ng;
+    }
+}
+
+// Moeller-Trumbore, no culling; edges inclusive; NaNs reject.  Written without early exits so that the two
+// triangles of a record overlap in the pipeline; every value is the one the exiting form would have computed.
+RT_DEV bool tri_test(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float tnear, float &t, float &u, float &v) {
+    V3 pv = cross(d, e2);
+    float det = dot(e1, pv);
+    float inv = 1.0f / det;
+    V3 tv = sub(o, v0);
+    u = dot(tv, pv) * inv;
+    V3 q = cross(tv, e1);
+    v = dot(d, q) * inv;
+    t = dot(e2, q) * inv;
+    return (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) && (t > tnear);
+}
+
+RT_DEV V3 select_corner(uint32_t s, V3 a, V3 b, V3 c, V3 d) {
+    const bool odd = (s & 1u) != 0u, high = (s & 2u) != 0u;
+    V3 lo = mk(odd ? b.x : a.x, odd ? b.y : a.y, odd ? b.z : a.z);
+    V3 hi = mk(odd ? d.x : c.x, odd ? d.y : c.y, odd ? d.z : c.z);
+    return mk(high ? hi.x : lo.x, high ? hi.y : lo.y, high ? hi.z : lo.z);
+}
+
+// Corners of triangle `which` (0 or 1) of a record, in the triangle's own vertex order.
+RT_DEV void record_corners(F4 r0, F4 r1, F4 r2, uint32_t code, uint32_t which, V3 &v0, V3 &v1, V3 &v2) {
+    V3 a = mk(r0.x, r0.y, r0.z), b = mk(r0.w, r1.x, r1.y), c = mk(r1.z, r1.w, r2.x), d = mk(r2.y, r2.z, r2.w);
+    if (which == 0u) {
+        v0 = a;
+        v1 = b;
+        v2 = c;
+    } else {
+        v0 = select_corner(code >> 24, a, b, c, d);
+        v1 = select_corner(code >> 26, a, b, c, d);
+        v2 = select_corner(code >> 28, a, b, c, d);
+    }
+}
+
+// Tests every primitive of one record.  Closest::slot = 2 * record slot + triangle.
 RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnear, Closest &best) {
     const F4 *p = sv.prims + (size_t)slot * RT_PRIM_F4;
-    F4 a = p[0], b = p[1], c = p[2];
-    uint32_t gidx = __builtin_bit_cast(uint32_t, c.y);
-    uint32_t geom = __builtin_bit_cast(uint32_t, c.z);
-    float t, u = 0.0f, v = 0.0f;
-    V3 ng = mk(0.0f, 0.0f, 0.0f);
-    if (geom & RT_SPHERE) {
+    F4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+    const uint32_t gidx0 = __builtin_bit_cast(uint32_t, r3.x), gidx1 = __builtin_bit_cast(uint32_t, r3.y);
+    const uint32_t code = __builtin_bit_cast(uint32_t, r3.z);
+    if (code & RT_SPHERE) {
         // Embree's sphere-point formulation: project the centre on the ray, compare the perpendicular distance
         // with the radius; Ng = hit - centre = -+td * d - perp.
-        V3 centre = mk(a.x, a.y, a.z);
-        float radius = a.w;
+        V3 centre = mk(r0.x, r0.y, r0.z);
+        float radius = r0.w;
         float rd2 = 1.0f / dot(d, d);
         V3 c0 = sub(centre, o);
         float proj = dot(c0, d) * rd2;
         V3 perp = sub(c0, scale(proj, d));
         float l2 = dot(perp, perp);
-        float r2 = radius * radius;
-        if (!(l2 <= r2)) return;
-        float td = sqrtf((r2 - l2) * rd2);
+        float r2s = radius * radius;
+        if (!(l2 <= r2s)) return;
+        float td = sqrtf((r2s - l2) * rd2);
         float t_front = proj - td;
         float t_back = proj + td;
+        float t;
+        V3 ng;
         if (tnear <= t_front && t_front <= best.t) {
             t = t_front;
             ng = sub(scale(-td, d), perp);
@@ -514,32 +567,18 @@ RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnea
         } else {
             return;
         }
-    } else {
-        // Moeller-Trumbore, no culling; edges inclusive; NaNs reject.
-        V3 v0 = mk(a.x, a.y, a.z);
-        V3 e1 = mk(a.w, b.x, b.y);
-        V3 e2 = mk(b.z, b.w, c.x);
-        V3 pv = cross(d, e2);
-        float det = dot(e1, pv);
-        if (!(det != 0.0f)) return;
-        float inv = 1.0f / det;
-        V3 tv = sub(o, v0);
-        u = dot(tv, pv) * inv;
-        if (!(u >= 0.0f && u <= 1.0f)) return;
-        V3 q = cross(tv, e1);
-        v = dot(d, q) * inv;
-        if (!(v >= 0.0f && u + v <= 1.0f)) return;
-        t = dot(e2, q) * inv;
-        if (!(t > tnear)) return;
+        take_candidate(t, gidx0, 2u * slot, 0.0f, 0.0f, ng, true, best);
+        return;
     }
-    if (t < best.t || (t == best.t && gidx < best.gidx)) {
-        best.t = t;
-        best.gidx = gidx;
-        best.slot = slot;
-        best.u = u;
-        best.v = v;
-        best.ng = ng;
-    }
+    V3 a0, a1, a2, b0, b1, b2;
+    record_corners(r0, r1, r2, code, 0u, a0, a1, a2);
+    record_corners(r0, r1, r2, code, 1u, b0, b1, b2);
+    float ta, ua, va, tb, ub, vb;
+    const bool oka = tri_test(a0, sub(a1, a0), sub(a2, a0), o, d, tnear, ta, ua, va);
+    const bool okb = tri_test(b0, sub(b1, b0), sub(b2, b0), o, d, tnear, tb, ub, vb) && gidx1 != RT_EMPTY;
+    const V3 zero = mk(0.0f, 0.0f, 0.0f);
+    take_candidate(ta, gidx0, 2u * slot, ua, va, zero, oka, best);
+    take_candidate(tb, gidx1, 2u * slot + 1u, ub, vb, zero, okb, best);
 }
 
 // Reciprocal that never produces inf, so that 0 * inv is 0 and not NaN in the slab test.
@@ -575,21 +614,28 @@ RT_DEV void trav_begin(const SceneView &sv, V3 o, V3 d, float tfar, Trav &tr) {
 // padded at build time), so it uses fused multiply-adds; it never decides a hit.
 template <class Stack>
 RT_DEV void trav_node_step(const SceneView &sv, float tnear, Trav &tr, Stack &st) {
-    const F4 *n = sv.nodes + (size_t)tr.cur * RT_NODE_F4;
-    const F4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5];
-    const F4 cf = n[6];
-    const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, lys[4] = {ly.x, ly.y, ly.z, ly.w};
-    const float lzs[4] = {lz.x, lz.y, lz.z, lz.w}, hxs[4] = {hx.x, hx.y, hx.z, hx.w};
-    const float hys[4] = {hy.x, hy.y, hy.z, hy.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
-    const uint32_t ch[4] = {__builtin_bit_cast(uint32_t, cf.x), __builtin_bit_cast(uint32_t, cf.y),
-                            __builtin_bit_cast(uint32_t, cf.z), __builtin_bit_cast(uint32_t, cf.w)};
+    const U4 *n = reinterpret_cast<const U4 *>(sv.nodes) + (size_t)tr.cur * RT_NODE_F4;
+    const U4 w0 = n[0], w1 = n[1], w2 = n[2], w3 = n[3];
+    const uint32_t ch[4] = {w3.x, w3.y, w3.z, w3.w};
+    // plane distance = (origin + q * step - o) / d = q * (step / d) + (origin / d - o / d)
+    const float sx = __builtin_bit_cast(float, w0.w) * tr.ix;
+    const float sy = __builtin_bit_cast(float, w1.x) * tr.iy;
+    const float sz = __builtin_bit_cast(float, w1.y) * tr.iz;
+    const float bx = __builtin_fmaf(__builtin_bit_cast(float, w0.x), tr.ix, tr.nox);
+    const float by = __builtin_fmaf(__builtin_bit_cast(float, w0.y), tr.iy, tr.noy);
+    const float bz = __builtin_fmaf(__builtin_bit_cast(float, w0.z), tr.iz, tr.noz);
+    const uint32_t qlx = w1.z, qly = w1.w, qlz = w2.x, qhx = w2.y, qhy = w2.z, qhz = w2.w;
     const float tfar = tr.best.t;
     float tn[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float t0x = __builtin_fmaf(lxs[k], tr.ix, tr.nox), t1x = __builtin_fmaf(hxs[k], tr.ix, tr.nox);
-        const float t0y = __builtin_fmaf(lys[k], tr.iy, tr.noy), t1y = __builtin_fmaf(hys[k], tr.iy, tr.noy);
-        const float t0z = __builtin_fmaf(lzs[k], tr.iz, tr.noz), t1z = __builtin_fmaf(hzs[k], tr.iz, tr.noz);
+        const int sh = 8 * k;
+        const float t0x = __builtin_fmaf((float)((qlx >> sh) & 255u), sx, bx);
+        const float t1x = __builtin_fmaf((float)((qhx >> sh) & 255u), sx, bx);
+        const float t0y = __builtin_fmaf((float)((qly >> sh) & 255u), sy, by);
+        const float t1y = __builtin_fmaf((float)((qhy >> sh) & 255u), sy, by);
+        const float t0z = __builtin_fmaf((float)((qlz >> sh) & 255u), sz, bz);
+        const float t1z = __builtin_fmaf((float)((qhz >> sh) & 255u), sz, bz);
         const float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tnear));
         const float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tfar));
         const bool hit = (ch[k] != RT_EMPTY) && (tmin <= tmax * 1.0000004f);
@@ -680,19 +726,23 @@ RT_DEV void finish_hit(const SceneView &sv, V3 o, V3 d, const Closest &best, Hit
         h.mat_id = 0;
         return;
     }
-    const F4 *p = sv.prims + (size_t)best.slot * RT_PRIM_F4;
-    F4 a = p[0], b = p[1], c = p[2];
-    uint32_t geom = __builtin_bit_cast(uint32_t, c.z);
+    const F4 *p = sv.prims + (size_t)(best.slot >> 1) * RT_PRIM_F4;
+    F4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+    const uint32_t code = __builtin_bit_cast(uint32_t, r3.z);
     V3 ng = best.ng;
-    if (!(geom & RT_SPHERE)) ng = cross(mk(a.w, b.x, b.y), mk(b.z, b.w, c.x));
+    if (!(code & RT_SPHERE)) {
+        V3 v0, v1, v2;
+        record_corners(r0, r1, r2, code, best.slot & 1u, v0, v1, v2);
+        ng = cross(sub(v1, v0), sub(v2, v0));
+    }
     h.hit = true;
     h.t = best.t;
     h.pos = mk(o.x + best.t * d.x, o.y + best.t * d.y, o.z + best.t * d.z);
     h.n = normalize_or_zero(ng);
     h.u = best.u;
     h.v = best.v;
-    h.geom_id = geom & ~RT_SPHERE;
-    h.prim_id = __builtin_bit_cast(uint32_t, c.w);
+    h.geom_id = code & RT_GEOM_MASK;
+    h.prim_id = best.gidx - __builtin_bit_cast(uint32_t, r3.w);
     h.mat_id = h.geom_id < sv.n_geoms ? sv.geom_material[h.geom_id] : 0u;
     if (h.mat_id >= sv.n_materials) h.mat_id = 0u;
 }

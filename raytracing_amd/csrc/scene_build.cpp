@@ -4,6 +4,10 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
 namespace rts {
 
 namespace {
@@ -58,6 +62,125 @@ void apply_transform(const float translation[3], const float scale[3], const flo
     p[2] = scale[2] * rz + translation[2];
 }
 
+namespace {
+
+// ---- triangle pairing ----------------------------------------------------------------------------------------
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct EdgeRef {
+    uint64_t key;
+    uint32_t tri;
+    uint32_t edge;
+};
+
+inline const float *corner(const HostPrim &p, int k) { return k == 0 ? p.a : (k == 1 ? p.b : p.c); }
+inline bool same_point(const float *x, const float *y) { return memcmp(x, y, 12) == 0; }
+
+inline uint64_t mix64(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xFF51AFD7ED558CCDull;
+    return h ^ (h >> 33);
+}
+
+// key of the undirected edge between corners k and k + 1 of triangle p: geometry and both end points, bit for bit
+uint64_t edge_key(const HostPrim &p, int k) {
+    const float *x = corner(p, k), *y = corner(p, (k + 1) % 3);
+    if (memcmp(x, y, 12) > 0) std::swap(x, y);
+    uint32_t w[6];
+    memcpy(w, x, 12);
+    memcpy(w + 3, y, 12);
+    uint64_t h = p.geom;
+    for (int i = 0; i < 6; i += 2) h = mix64(h, ((uint64_t)w[i] << 32) | w[i + 1]);
+    return h;
+}
+
+bool same_edge(const HostPrim &p, int pe, const HostPrim &q, int qe) {
+    if (p.geom != q.geom) return false;
+    const float *p0 = corner(p, pe), *p1 = corner(p, (pe + 1) % 3);
+    const float *q0 = corner(q, qe), *q1 = corner(q, (qe + 1) % 3);
+    return (same_point(p0, q0) && same_point(p1, q1)) || (same_point(p0, q1) && same_point(p1, q0));
+}
+
+// Sorts edge references by key: bucket by the top byte, then sort the buckets on worker threads.
+void sort_edges(std::vector<EdgeRef> &v, unsigned threads) {
+    const size_t n = v.size();
+    if (n < (1u << 16) || threads < 2) {
+        std::sort(v.begin(), v.end(), [](const EdgeRef &x, const EdgeRef &y) { return x.key < y.key; });
+        return;
+    }
+    std::vector<size_t> start(257, 0);
+    for (const EdgeRef &e : v) ++start[(e.key >> 56) + 1];
+    for (int b = 0; b < 256; ++b) start[b + 1] += start[b];
+    std::vector<EdgeRef> tmp(n);
+    {
+        std::vector<size_t> at(start.begin(), start.end() - 1);
+        for (const EdgeRef &e : v) tmp[at[e.key >> 56]++] = e;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            for (int b; (b = next.fetch_add(1)) < 256;)
+                std::sort(tmp.begin() + start[b], tmp.begin() + start[b + 1],
+                          [](const EdgeRef &x, const EdgeRef &y) { return x.key < y.key; });
+        });
+    for (auto &th : pool) th.join();
+    v.swap(tmp);
+}
+
+// mate[i] = the triangle that shares a record with triangle i, or NONE.  Two triangles of one geometry that share an
+// edge (same end points, bit for bit) have at most four distinct corners between them; among the free neighbours of a
+// triangle the one with the smallest common box is taken.
+void pair_triangles(const std::vector<HostPrim> &prims, const std::vector<rtb::Box> &boxes, std::vector<uint32_t> &mate) {
+    const size_t n = prims.size();
+    mate.assign(n, NONE);
+    std::vector<EdgeRef> edges;
+    edges.reserve(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        if (prims[i].is_sphere) continue;
+        for (int k = 0; k < 3; ++k) edges.push_back(EdgeRef{edge_key(prims[i], k), (uint32_t)i, (uint32_t)k});
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    if (hw > 16) hw = 16;
+    sort_edges(edges, hw);
+    std::vector<uint32_t> adj(3 * n, NONE);
+    for (size_t k = 0; k + 1 < edges.size();) {
+        const EdgeRef &x = edges[k], &y = edges[k + 1];
+        if (x.key == y.key && x.tri != y.tri && same_edge(prims[x.tri], (int)x.edge, prims[y.tri], (int)y.edge)) {
+            adj[3 * (size_t)x.tri + x.edge] = y.tri;
+            adj[3 * (size_t)y.tri + y.edge] = x.tri;
+            k += 2;
+        } else {
+            ++k;
+        }
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (mate[i] != NONE || prims[i].is_sphere) continue;
+        uint32_t best = NONE;
+        float best_area = INFINITY;
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t j = adj[3 * i + k];
+            if (j == NONE || mate[j] != NONE) continue;
+            float area = 0.0f, ext[3];
+            for (int a = 0; a < 3; ++a)
+                ext[a] = fmaxf(boxes[i].hi[a], boxes[j].hi[a]) - fminf(boxes[i].lo[a], boxes[j].lo[a]);
+            area = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];
+            if (!(area >= best_area)) {
+                best_area = area;
+                best = j;
+            }
+        }
+        if (best != NONE) {
+            mate[i] = best;
+            mate[best] = (uint32_t)i;
+        }
+    }
+}
+
+} // namespace
+
 bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, std::vector<rtd::F4> &records, float lo[3],
                  float hi[3], const std::function<bool(double)> &progress) {
     const size_t n = prims.size();
@@ -77,28 +200,78 @@ bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, std::vec
     for (int k = 0; k < 3; ++k)
         if (n) scene_scale = fmaxf(scene_scale, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
     for (size_t i = 0; i < n; ++i) pad_box(boxes[i], scene_scale);
-    if (!rtb::build(boxes, bvh, progress)) return false;
-    records.assign(n * rtd::RT_PRIM_F4, rtd::F4{0.0f, 0.0f, 0.0f, 0.0f});
-    for (size_t slot = 0; slot < n; ++slot) {
-        const uint32_t gi = bvh.prim_order[slot];
-        const HostPrim &p = prims[gi];
-        float w[12];
-        if (p.is_sphere) {
-            w[0] = p.a[0];
-            w[1] = p.a[1];
-            w[2] = p.a[2];
-            w[3] = p.b[0];
-            for (int k = 4; k < 9; ++k) w[k] = 0.0f;
-        } else {
+    if (progress && !progress(0.0)) return false;
+
+    // records: a triangle with its mate, a lone triangle, or a sphere; in insertion order of their first primitive
+    std::vector<uint32_t> mate;
+    pair_triangles(prims, boxes, mate);
+    std::vector<uint32_t> rec_first;
+    rec_first.reserve(n / 2 + 16);
+    for (size_t i = 0; i < n; ++i)
+        if (mate[i] == NONE || mate[i] > i) rec_first.push_back((uint32_t)i);
+    const size_t nr = rec_first.size();
+    std::vector<rtb::Box> rec_boxes(nr);
+    for (size_t r = 0; r < nr; ++r) {
+        const uint32_t i = rec_first[r], j = mate[i];
+        rec_boxes[r] = boxes[i];
+        if (j != NONE)
             for (int k = 0; k < 3; ++k) {
-                w[k] = p.a[k];
-                w[3 + k] = p.b[k] - p.a[k];
-                w[6 + k] = p.c[k] - p.a[k];
+                rec_boxes[r].lo[k] = fminf(rec_boxes[r].lo[k], boxes[j].lo[k]);
+                rec_boxes[r].hi[k] = fmaxf(rec_boxes[r].hi[k], boxes[j].hi[k]);
+            }
+    }
+    // first global primitive index of every geometry (primitives of a geometry are consecutive)
+    std::vector<uint32_t> geom_first;
+    for (size_t i = 0; i < n; ++i) {
+        if (prims[i].geom >= geom_first.size()) geom_first.resize(prims[i].geom + 1, NONE);
+        if (geom_first[prims[i].geom] == NONE) geom_first[prims[i].geom] = (uint32_t)i;
+    }
+    if (!rtb::build(rec_boxes, bvh, progress)) return false;
+    records.assign(nr * rtd::RT_PRIM_F4, rtd::F4{0.0f, 0.0f, 0.0f, 0.0f});
+    for (size_t slot = 0; slot < nr; ++slot) {
+        const uint32_t i = rec_first[bvh.prim_order[slot]], j = mate[i];
+        const HostPrim &p = prims[i];
+        float w[16];
+        for (int k = 0; k < 16; ++k) w[k] = 0.0f;
+        uint32_t ids[4] = {i, NONE, p.geom & rtd::RT_GEOM_MASK, geom_first[p.geom]};
+        if (p.is_sphere) {
+            memcpy(&w[0], p.a, 12);
+            w[3] = p.b[0];
+            ids[2] |= rtd::RT_SPHERE;
+        } else {
+            memcpy(&w[0], p.a, 12);
+            memcpy(&w[3], p.b, 12);
+            memcpy(&w[6], p.c, 12);
+            if (j != NONE) {
+                const HostPrim &q = prims[j];
+                uint32_t code = 0;
+                bool have_d = false, ok = true;
+                for (int k = 0; k < 3; ++k) {
+                    const float *x = corner(q, k);
+                    uint32_t sel;
+                    if (same_point(x, p.a))
+                        sel = 0;
+                    else if (same_point(x, p.b))
+                        sel = 1;
+                    else if (same_point(x, p.c))
+                        sel = 2;
+                    else if (!have_d || same_point(x, &w[9])) {
+                        memcpy(&w[9], x, 12);
+                        have_d = true;
+                        sel = 3;
+                    } else {
+                        ok = false;
+                        sel = 0;
+                    }
+                    code |= sel << (2 * k);
+                }
+                if (!ok) return false; // cannot happen: mates share an edge
+                ids[1] = j;
+                ids[2] |= code << 24;
             }
         }
-        const uint32_t ids[3] = {gi, p.geom | (p.is_sphere ? rtd::RT_SPHERE : 0u), p.prim};
-        memcpy(&w[9], ids, 12);
-        memcpy(&records[slot * rtd::RT_PRIM_F4], w, 48);
+        memcpy(&w[12], ids, 16);
+        memcpy(&records[slot * rtd::RT_PRIM_F4], w, 64);
     }
     return true;
 }

@@ -1,5 +1,5 @@
 // scene_build.h -- host-side scene assembly shared by the C ABI: primitive records, padded culling boxes, BVH build
-// and the 48-byte primitive layout the kernels read.  No HIP dependency.
+// and the 64-byte primitive records (two triangles that share an edge, a lone triangle or a sphere) the kernels read.  No HIP dependency.
 #pragma once
 
 #include <functional>
@@ -18,8 +18,8 @@ struct HostPrim {
 // Transformer<Point>::apply (crates/rt/src/math/transform.rs:45-52) with glam's Quat * Vec3, in f32.
 void apply_transform(const float translation[3], const float scale[3], const float rot[4], float p[3]);
 
-// Builds the BVH over `prims` (global primitive index = position in the vector) and lays the primitives out in leaf
-// order.  lo/hi receive the unpadded scene bounds.  Returns false when the progress callback cancels.
+// Pairs triangles into records, builds the BVH over the records (global primitive index = position in `prims`;
+// the primitives of one geometry must be consecutive) and lays the records out in leaf order.  lo/hi receive the unpadded scene bounds.  Returns false when the progress callback cancels.
 bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, std::vector<rtd::F4> &records, float lo[3],
                  float hi[3], const std::function<bool(double)> &progress);
 

@@ -332,4 +332,6 @@ void hs_depth_stats(void *p, const CameraView *cam, const Params *prm, const uin
         }
 }
 
+const void *hs_view(void *p) { return &((Scene *)p)->view; }
+
 } // extern "C"
