@@ -10,8 +10,10 @@
 namespace rtk {
 
 constexpr int BLOCK = 256;
-constexpr int STATE_PLANES = 23; // per-path SoA planes, see RenderArgs::state
+constexpr int STATE_PLANES = 14; // per-path SoA planes, see RenderArgs::state
+constexpr int PAYLOAD_PLANES = 11; // per-queue-entry SoA planes, see RenderArgs::payload
 constexpr int ACCUM_PLANES = 22;
+constexpr int HIT_PLANES = 5;
 constexpr int RESOLVE_PLANES = 15;
 constexpr uint32_t MAX_STACK = 160; // deepest tree the kernels accept (entries of traversal stack)
 constexpr int PIXEL_BLOCK = 64;     // pixels whose samples are adjacent in path-id space (one wave of primary rays)
@@ -45,10 +47,12 @@ struct RenderArgs {
     rtd::SceneView scene;
     rtd::CameraView camera;
     const uint32_t *pixels; // n_pixels x (x, y)
-    float *state;           // STATE_PLANES planes of n_paths floats:
-                            //   0-2 origin, 3-5 direction, 6-8 beta, 9-11 radiance, 12-14 normal, 15-17 position,
-                            //   18-20 albedo, 21 z, 22 ray_depth
-    uint32_t *queue[2];     // live path ids, ping-pong by bounce parity; segment x at queue[.] + x * seg_cap
+    float *state;           // STATE_PLANES planes of n_paths floats, indexed by path id:
+                            //   0-2 radiance, 3-5 normal, 6-8 position, 9-11 albedo, 12 z, 13 ray_depth
+    float *hits;            // HIT_PLANES planes of SEGMENTS * seg_cap: t, Ng.xyz, geometry word of every queue entry's hit
+    float *payload[2];      // the rays of a bounce in queue order, ping-pong by bounce parity: PAYLOAD_PLANES planes of
+                            // SEGMENTS * seg_cap, segment x at x * seg_cap: 0 path id (bits), 1-3 origin, 4-6 direction,
+                            // 7-9 beta, 10 ray_depth so far.  Bounce 0 has an implicit queue (every path in id order).
     uint32_t *counts;       // counts[(d * SEGMENTS + x) * COUNTER_STRIDE] = live paths of segment x entering bounce d
                             // (d >= 1); zeroed before the pass
     uint32_t *work;         // work[(d * SEGMENTS + x) * COUNTER_STRIDE] = next unclaimed position of that queue; zeroed
@@ -60,7 +64,7 @@ struct RenderArgs {
     uint32_t seg_cap;     // queue entries per segment
     uint32_t n_paths;     // n_blocks * PIXEL_BLOCK * samples
     uint32_t claim;       // queue entries a wave claims with one atomic (a multiple of 64)
-    int32_t refill_below; // a wave stops traversing to shade and refill when fewer lanes than this are busy
+    int32_t refill_below; // a traversal wave flushes finished lanes and refills when fewer lanes than this are busy
     int32_t leaf_bias;    // a primitive-test step is run when leaf lanes + bias > node lanes
     float allowed_error;  // > 0: a pixel stops accumulating within this pass once its colour error is below it
     uint32_t sample_base; // first sample index of the pass
@@ -73,7 +77,10 @@ struct RenderArgs {
 // d_spill must hold max(0, stack_need - LDS_STACK) * grid_blocks * BLOCK entries (stack_need = the tree's worst case).
 int launch_intersect(const rtd::SceneView &scene, const RayAoS *d_rays, HitAoS *d_hits, size_t n, uint32_t *d_spill,
                      uint32_t grid_blocks, void *stream);
-int launch_bounce(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream);
+int launch_extend(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream);
+// one thread per queue entry; max_segment_entries = the longest segment's entry count at this bounce
+int launch_shade(const RenderArgs &args, uint32_t depth, uint32_t max_segment_entries, void *stream);
+int extend_blocks_per_cu(); // resident blocks of the traversal kernel per CU (occupancy query)
 int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, void *stream);
 int launch_resolve(const float *d_accum, uint32_t n_pixels, float *d_out, int srgb, void *stream);
 

@@ -1,15 +1,15 @@
 // kernels.hip -- gfx950 kernels of the wavefront path tracer.
 //
 //   intersect_kernel   batch closest hit (Shape::intersection_full for n rays)
-//   bounce_kernel      one bounce of every live path: [camera ray at bounce 0] -> closest hit -> shade -> next ray,
-//                      then wave-level compaction of the survivors into the next bounce's queue
+//   extend_kernel      closest hit of every live path's ray (camera rays are generated here at bounce 0)
+//   shade_kernel       scatter / terminate every path from its hit record, compact the survivors into the next
+//                      bounce's queue
 //   accumulate_kernel  adds a pass's samples to the per-pixel accumulators, in sample order
 //   resolve_kernel     accumulators -> the seven output channels
 //
 // One ray per lane.  The traversal stack lives in LDS, one column per lane (stack[entry][lane], bank = lane), so a
-// push or pop is one conflict-free ds_write_b32 / ds_read_b32.  Waves claim 64 queue entries at a time with one
-// atomic on a per-bounce cursor and publish survivors with one atomic per wave (ballot + popcount give each lane its
-// rank).  There is no barrier anywhere: waves never wait for each other.
+// push or pop is one conflict-free ds_write_b32 / ds_read_b32.  Traversal waves claim batches of queue entries with
+// one atomic on a per-bounce cursor and never wait for each other.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -81,181 +81,168 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const
     }
 }
 
-// Lanes refill themselves: a lane whose ray has finished traversal shades it, publishes the continuation and takes the
-// next queue entry, while the other lanes of the wave keep their rays.  To keep both halves efficient the wave only
-// leaves the traversal loop when fewer than RenderArgs::refill_below lanes are still traversing (or the queue is
-// drained and nothing is left), so traversal runs with most lanes busy and shading runs for a batch of lanes at a time.
-
 // XCC_ID hardware register (bits 3:0): the XCD this wave runs on.  Used for locality only, never for correctness.
 __device__ __forceinline__ uint32_t xcd_of_wave() {
     return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (uint32_t)(SEGMENTS - 1);
 }
 
-__global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t depth) {
+// Entry i of segment seg at bounce `depth` -> path id, pixel and sample.  At bounce 0 the queue is implicit (every
+// path of the segment's pixel blocks, sample-major inside a block; entries of pixels past n_pixels are padding).
+struct Entry {
+    uint32_t pid, pix, sample;
+    bool valid;
+};
+__device__ __forceinline__ Entry queue_entry(const RenderArgs &a, uint32_t depth, uint32_t seg, uint32_t i,
+                                             const float *__restrict__ q_in) {
+    const uint32_t per_block = a.samples * (uint32_t)PIXEL_BLOCK;
+    Entry e;
+    if (depth == 0u) {
+        const uint32_t lb = i / per_block, rem = i - lb * per_block;
+        const uint32_t blk = lb * (uint32_t)SEGMENTS + seg;
+        e.pix = blk * (uint32_t)PIXEL_BLOCK + rem % (uint32_t)PIXEL_BLOCK;
+        e.pid = blk * per_block + rem;
+        e.sample = a.sample_base + rem / (uint32_t)PIXEL_BLOCK;
+        e.valid = e.pix < a.n_pixels;
+    } else {
+        e.pid = __builtin_bit_cast(uint32_t, q_in[i]);
+        const uint32_t blk = e.pid / per_block, rem = e.pid - blk * per_block;
+        e.pix = blk * (uint32_t)PIXEL_BLOCK + rem % (uint32_t)PIXEL_BLOCK;
+        e.sample = a.sample_base + rem / (uint32_t)PIXEL_BLOCK;
+        e.valid = true;
+    }
+    return e;
+}
+
+__device__ __forceinline__ uint32_t segment_entries(const RenderArgs &a, uint32_t depth, uint32_t seg) {
+    if (depth == 0u) {
+        const uint32_t seg_blocks = a.n_blocks > seg ? (a.n_blocks - seg + (uint32_t)SEGMENTS - 1u) / (uint32_t)SEGMENTS : 0u;
+        return seg_blocks * a.samples * (uint32_t)PIXEL_BLOCK;
+    }
+    return a.counts[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE];
+}
+
+// Closest hit of every ray of one bounce.  Waves are persistent: a lane whose ray has finished writes its hit record
+// and takes the next queue entry while the other lanes of the wave keep their rays, so the traversal loop runs with
+// most lanes busy.  Finished lanes are flushed and refilled in batches (when fewer than RenderArgs::refill_below lanes
+// are busy), since that code runs for the idle lanes only.  Every step the wave runs the one phase -- inner-node test
+// or primitive test -- that most of its busy lanes are waiting for.
+//
+// Hit record of queue entry i of segment x, at plane offset x * seg_cap + i: distance (+inf = miss), geometric normal
+// (not normalised), geometry word.  Rays come from the bounce's payload planes, in queue order; at bounce 0 the camera
+// ray is generated here and stored there for the shading kernel.
+__global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t depth) {
     __shared__ uint32_t lds[LDS_STACK * BLOCK];
     LaneStack st = make_stack(lds, a.spill);
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const size_t P = a.n_paths;
-    float *__restrict__ S = a.state;
+    const size_t H = (size_t)SEGMENTS * a.seg_cap;
+    float *__restrict__ hits = a.hits;
+    float *__restrict__ Q = a.payload[depth & 1u]; // this bounce's rays, in queue order
     uint32_t nodes = 0, tests = 0;
     const bool count_visits = a.visit_counters != nullptr;
-    const uint32_t per_block = a.samples * (uint32_t)PIXEL_BLOCK; // paths of one pixel block
     const uint32_t home = xcd_of_wave();
 
     for (uint32_t turn = 0; turn < (uint32_t)SEGMENTS; ++turn) {
         const uint32_t seg = (home + turn) & (uint32_t)(SEGMENTS - 1);
-        // blocks seg, seg + SEGMENTS, ... belong to this segment
-        const uint32_t seg_blocks = a.n_blocks > seg ? (a.n_blocks - seg + (uint32_t)SEGMENTS - 1u) / (uint32_t)SEGMENTS : 0u;
-        const uint32_t n_in =
-            (depth == 0u) ? seg_blocks * per_block : a.counts[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE];
-        const uint32_t *__restrict__ q_in = a.queue[depth & 1u] + (size_t)seg * a.seg_cap;
-        uint32_t *__restrict__ q_out = a.queue[(depth + 1u) & 1u] + (size_t)seg * a.seg_cap;
+        const uint32_t n_in = segment_entries(a, depth, seg);
         uint32_t *cursor = &a.work[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE];
-        uint32_t *out_count = &a.counts[(size_t)((depth + 1u) * SEGMENTS + seg) * COUNTER_STRIDE];
         uint32_t c_next = 0, c_end = 0; // wave-uniform: the part of the queue this wave has claimed and not yet used
+        bool drained = n_in == 0u;      // wave-uniform: the segment has no unclaimed entries left
 
         bool has_ray = false;
-        bool drained = n_in == 0u; // wave-uniform: the segment has no unclaimed entries left
-        uint32_t pid = 0, x = 0, y = 0, sample = 0;
-        V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f), beta = mk(0.0f, 0.0f, 0.0f);
+        uint32_t slot_out = 0; // where this lane's hit record goes
+        V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f);
         Trav tr;
         tr.cur = RT_EMPTY;
 
         for (;;) {
-            // ---- shade the lanes whose traversal is complete
-            bool alive = false;
-            if (has_ray && tr.cur == RT_EMPTY) {
-                HitInfo h;
-                finish_hit(a.scene, org, dir, tr.best, h);
-                VertexOut vo;
-                bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, x, y, sample, depth, org, dir, beta, vo);
-                if (depth == 0u) {
-                    S[12 * P + pid] = vo.normal.x;
-                    S[13 * P + pid] = vo.normal.y;
-                    S[14 * P + pid] = vo.normal.z;
-                    S[15 * P + pid] = vo.position.x;
-                    S[16 * P + pid] = vo.position.y;
-                    S[17 * P + pid] = vo.position.z;
-                    S[18 * P + pid] = vo.albedo.x;
-                    S[19 * P + pid] = vo.albedo.y;
-                    S[20 * P + pid] = vo.albedo.z;
-                    S[21 * P + pid] = vo.z;
-                    S[22 * P + pid] = 0.0f + vo.t_add;
-                } else if (h.hit && vo.t_add != 0.0f) {
-                    S[22 * P + pid] = S[22 * P + pid] + vo.t_add;
+            const bool busy = has_ray && tr.cur != RT_EMPTY;
+            const int n_busy = (int)__popcll(__ballot(busy));
+            bool more = !drained || c_next != c_end;
+            if (n_busy == 0 || n_busy < a.refill_below) {
+                // ---- flush the finished lanes
+                if (has_ray && !busy) {
+                    float t = INFINITY;
+                    V3 ng = mk(0.0f, 0.0f, 0.0f);
+                    uint32_t code = RT_EMPTY, geom_first;
+                    if (tr.best.gidx != RT_EMPTY) {
+                        t = tr.best.t;
+                        ng = candidate_normal(a.scene, tr.best.slot, org, dir, t, code, geom_first);
+                    }
+                    hits[0 * H + slot_out] = t;
+                    hits[1 * H + slot_out] = ng.x;
+                    hits[2 * H + slot_out] = ng.y;
+                    hits[3 * H + slot_out] = ng.z;
+                    hits[4 * H + slot_out] = __builtin_bit_cast(float, code);
+                    has_ray = false;
                 }
-                if (cont && depth + 1u == a.max_depth) {
-                    // the next vertex would be at the depth limit: it contributes beta * 0 (pathtracing.rs:24-26)
-                    vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
-                    cont = false;
-                }
-                if (cont) {
-                    S[0 * P + pid] = org.x;
-                    S[1 * P + pid] = org.y;
-                    S[2 * P + pid] = org.z;
-                    S[3 * P + pid] = dir.x;
-                    S[4 * P + pid] = dir.y;
-                    S[5 * P + pid] = dir.z;
-                    S[6 * P + pid] = beta.x;
-                    S[7 * P + pid] = beta.y;
-                    S[8 * P + pid] = beta.z;
-                    alive = true;
-                } else {
-                    S[9 * P + pid] = vo.radiance.x;
-                    S[10 * P + pid] = vo.radiance.y;
-                    S[11 * P + pid] = vo.radiance.z;
-                }
-                has_ray = false;
-            }
-            // ---- publish survivors: one atomic per wave, lanes ranked by the ballot
-            const unsigned long long amask = __ballot(alive);
-            if (amask != 0ull) {
-                uint32_t obase = 0;
-                if (lane == 0) obase = atomicAdd(out_count, (uint32_t)__popcll(amask));
-                obase = __builtin_amdgcn_readfirstlane(obase);
-                if (alive) q_out[obase + (uint32_t)__popcll(amask & below)] = pid;
-            }
-            // ---- refill idle lanes from the wave's claimed range; claim the next a.claim entries with one atomic
-            // when the range is used up
-            if (c_next == c_end && !drained) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, a.claim);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n_in) {
-                    drained = true;
-                } else {
-                    c_next = base;
-                    c_end = min(base + a.claim, n_in);
-                    if (c_end == n_in) drained = true;
-                }
-            }
-            if (c_next != c_end) {
-                const unsigned long long nmask = __ballot(!has_ray);
-                const uint32_t i = c_next + (uint32_t)__popcll(nmask & below);
-                const bool take = !has_ray && i < c_end;
-                c_next = min(c_end, c_next + (uint32_t)__popcll(nmask));
-                if (take) {
-                    bool valid = true;
-                    uint32_t pix;
-                    if (depth == 0u) {
-                        // entry i of the segment: local block i / per_block, then sample-major inside the block
-                        const uint32_t lb = i / per_block, rem = i - lb * per_block;
-                        const uint32_t blk = lb * (uint32_t)SEGMENTS + seg;
-                        const uint32_t s_local = rem / (uint32_t)PIXEL_BLOCK, p = rem % (uint32_t)PIXEL_BLOCK;
-                        pix = blk * (uint32_t)PIXEL_BLOCK + p;
-                        pid = blk * per_block + rem;
-                        sample = a.sample_base + s_local;
-                        valid = pix < a.n_pixels;
+                // ---- refill idle lanes from the wave's claimed range; claim the next a.claim entries with one
+                // atomic when the range is used up
+                if (c_next == c_end && !drained) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(cursor, a.claim);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n_in) {
+                        drained = true;
                     } else {
-                        pid = q_in[i];
-                        const uint32_t blk = pid / per_block, rem = pid - blk * per_block;
-                        pix = blk * (uint32_t)PIXEL_BLOCK + rem % (uint32_t)PIXEL_BLOCK;
-                        sample = a.sample_base + rem / (uint32_t)PIXEL_BLOCK;
-                    }
-                    if (valid) {
-                        x = a.pixels[2 * pix];
-                        y = a.pixels[2 * pix + 1];
-                        if (depth == 0u) {
-                            camera_ray(a.camera, a.strata, a.seed, x, y, sample, org, dir);
-                            beta = mk(1.0f, 1.0f, 1.0f);
-                        } else {
-                            org = mk(S[0 * P + pid], S[1 * P + pid], S[2 * P + pid]);
-                            dir = mk(S[3 * P + pid], S[4 * P + pid], S[5 * P + pid]);
-                            beta = mk(S[6 * P + pid], S[7 * P + pid], S[8 * P + pid]);
-                        }
-                        st.sp = 0;
-                        trav_begin(a.scene, org, dir, INFINITY, tr);
-                        has_ray = true;
+                        c_next = base;
+                        c_end = min(base + a.claim, n_in);
+                        if (c_end == n_in) drained = true;
                     }
                 }
-            }
-            const bool more_to_claim = !drained || c_next != c_end;
-            if (__ballot(has_ray) == 0ull) {
-                if (!more_to_claim) break;
-                continue; // only padding entries were taken: take more
-            }
-            // ---- traverse while enough lanes are busy (all the way once nothing is left to take).  Every step the wave
-            // runs the one phase -- inner-node test or primitive test -- that most of its busy lanes are waiting for,
-            // so each step executes with at least half of the busy lanes.
-            const int keep_going = more_to_claim ? a.refill_below : 1;
-            for (;;) {
-                const bool busy = has_ray && tr.cur != RT_EMPTY;
-                const bool at_leaf = busy && (tr.cur & RT_LEAF) != 0u;
-                const bool at_node = busy && !at_leaf;
-                const int n_node = (int)__popcll(__ballot(at_node));
-                const int n_leaf = (int)__popcll(__ballot(at_leaf));
-                if (n_node + n_leaf < keep_going) break;
-                if (n_leaf == 0 || (n_node > 0 && n_node >= n_leaf + a.leaf_bias)) {
-                    if (at_node) {
-                        if (count_visits) ++nodes;
-                        trav_node_step(a.scene, RT_TNEAR, tr, st);
+                if (c_next != c_end) {
+                    const unsigned long long nmask = __ballot(!has_ray);
+                    const uint32_t i = c_next + (uint32_t)__popcll(nmask & below);
+                    const bool take = !has_ray && i < c_end;
+                    c_next = min(c_end, c_next + (uint32_t)__popcll(nmask));
+                    if (take) {
+                        const size_t pos = (size_t)seg * a.seg_cap + i;
+                        bool valid = true;
+                        if (depth == 0u) {
+                            const Entry e = queue_entry(a, depth, seg, i, nullptr);
+                            valid = e.valid;
+                            if (valid) {
+                                camera_ray(a.camera, a.strata, a.seed, a.pixels[2 * e.pix], a.pixels[2 * e.pix + 1], e.sample,
+                                           org, dir);
+                                Q[1 * H + pos] = org.x;
+                                Q[2 * H + pos] = org.y;
+                                Q[3 * H + pos] = org.z;
+                                Q[4 * H + pos] = dir.x;
+                                Q[5 * H + pos] = dir.y;
+                                Q[6 * H + pos] = dir.z;
+                            }
+                        } else {
+                            org = mk(Q[1 * H + pos], Q[2 * H + pos], Q[3 * H + pos]);
+                            dir = mk(Q[4 * H + pos], Q[5 * H + pos], Q[6 * H + pos]);
+                        }
+                        if (valid) {
+                            slot_out = (uint32_t)pos;
+                            st.sp = 0;
+                            trav_begin(a.scene, org, dir, INFINITY, tr);
+                            has_ray = true;
+                        }
                     }
-                } else {
-                    if (at_leaf) {
-                        if (count_visits) ++tests;
-                        trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
-                    }
+                }
+                more = !drained || c_next != c_end;
+                if (__ballot(has_ray) == 0ull) {
+                    if (!more) break;
+                    continue; // only padding entries were taken: take more
+                }
+            }
+            // ---- one traversal step
+            const bool at_leaf = has_ray && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
+            const bool at_node = has_ray && tr.cur != RT_EMPTY && !at_leaf;
+            const int n_node = (int)__popcll(__ballot(at_node));
+            const int n_leaf = (int)__popcll(__ballot(at_leaf));
+            if (n_leaf == 0 || (n_node > 0 && n_node >= n_leaf + a.leaf_bias)) {
+                if (at_node) {
+                    if (count_visits) ++nodes;
+                    trav_node_step(a.scene, RT_TNEAR, tr, st);
+                }
+            } else {
+                if (at_leaf) {
+                    if (count_visits) ++tests;
+                    trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
                 }
             }
         }
@@ -270,6 +257,120 @@ __global__ __launch_bounds__(BLOCK) void bounce_kernel(RenderArgs a, uint32_t de
             atomicAdd(reinterpret_cast<unsigned long long *>(a.visit_counters), (unsigned long long)nodes);
             atomicAdd(reinterpret_cast<unsigned long long *>(a.visit_counters) + 1, (unsigned long long)tests);
         }
+    }
+}
+
+// Shades every hit record of one bounce, one queue entry per thread: scatter or terminate the path, store the first
+// bounce's outputs, append the survivors to the next bounce's queue (one atomic per block).  Block b works on segment
+// b % SEGMENTS, so the blocks an XCD receives read what that XCD's waves mostly wrote.
+__global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t depth) {
+    __shared__ uint32_t wave_count[BLOCK / 64];
+    __shared__ uint32_t block_base;
+    const uint32_t seg = blockIdx.x % (uint32_t)SEGMENTS;
+    const uint32_t i = (blockIdx.x / (uint32_t)SEGMENTS) * (uint32_t)BLOCK + threadIdx.x;
+    const uint32_t n_in = segment_entries(a, depth, seg);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const size_t P = a.n_paths;
+    const size_t H = (size_t)SEGMENTS * a.seg_cap;
+    float *__restrict__ S = a.state;
+    const float *__restrict__ hits = a.hits;
+    const float *__restrict__ Q = a.payload[depth & 1u];
+    float *__restrict__ Qn = a.payload[(depth + 1u) & 1u];
+    const size_t pos = (size_t)seg * a.seg_cap + i;
+
+    bool alive = false;
+    uint32_t pid = 0;
+    V3 org, dir, beta;
+    float ray_depth = 0.0f;
+    if (i < n_in) {
+        const Entry e = queue_entry(a, depth, seg, i, Q + (size_t)seg * a.seg_cap);
+        pid = e.pid;
+        if (e.valid) {
+            org = mk(Q[1 * H + pos], Q[2 * H + pos], Q[3 * H + pos]);
+            dir = mk(Q[4 * H + pos], Q[5 * H + pos], Q[6 * H + pos]);
+            beta = mk(1.0f, 1.0f, 1.0f);
+            if (depth != 0u) {
+                beta = mk(Q[7 * H + pos], Q[8 * H + pos], Q[9 * H + pos]);
+                ray_depth = Q[10 * H + pos];
+            }
+            const uint32_t code = __builtin_bit_cast(uint32_t, hits[4 * H + pos]);
+            HitInfo h;
+            h.u = h.v = 0.0f;
+            h.prim_id = RT_EMPTY;
+            if (code == RT_EMPTY) {
+                h.hit = false;
+                h.t = INFINITY;
+                h.pos = mk(0.0f, 0.0f, 0.0f);
+                h.n = mk(0.0f, 0.0f, 0.0f);
+                h.geom_id = RT_EMPTY;
+                h.mat_id = 0;
+            } else {
+                h.hit = true;
+                h.t = hits[0 * H + pos];
+                h.pos = mk(org.x + h.t * dir.x, org.y + h.t * dir.y, org.z + h.t * dir.z);
+                h.n = normalize_or_zero(mk(hits[1 * H + pos], hits[2 * H + pos], hits[3 * H + pos]));
+                h.geom_id = code & RT_GEOM_MASK;
+                h.mat_id = h.geom_id < a.scene.n_geoms ? a.scene.geom_material[h.geom_id] : 0u;
+                if (h.mat_id >= a.scene.n_materials) h.mat_id = 0u;
+            }
+            VertexOut vo;
+            bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, a.pixels[2 * e.pix], a.pixels[2 * e.pix + 1], e.sample,
+                                     depth, org, dir, beta, vo);
+            if (depth == 0u) {
+                S[3 * P + pid] = vo.normal.x;
+                S[4 * P + pid] = vo.normal.y;
+                S[5 * P + pid] = vo.normal.z;
+                S[6 * P + pid] = vo.position.x;
+                S[7 * P + pid] = vo.position.y;
+                S[8 * P + pid] = vo.position.z;
+                S[9 * P + pid] = vo.albedo.x;
+                S[10 * P + pid] = vo.albedo.y;
+                S[11 * P + pid] = vo.albedo.z;
+                S[12 * P + pid] = vo.z;
+                ray_depth = 0.0f + vo.t_add;
+            } else if (h.hit && vo.t_add != 0.0f) {
+                ray_depth = ray_depth + vo.t_add;
+            }
+            if (cont && depth + 1u == a.max_depth) {
+                // the next vertex would be at the depth limit: it contributes beta * 0 (pathtracing.rs:24-26)
+                vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
+                cont = false;
+            }
+            if (cont) {
+                alive = true;
+            } else {
+                S[0 * P + pid] = vo.radiance.x;
+                S[1 * P + pid] = vo.radiance.y;
+                S[2 * P + pid] = vo.radiance.z;
+                S[13 * P + pid] = ray_depth;
+            }
+        }
+    }
+    // ---- survivors keep their queue order inside the block; one atomic per block reserves the range
+    const unsigned long long amask = __ballot(alive);
+    if (lane == 0) wave_count[wave] = (uint32_t)__popcll(amask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) total += wave_count[w];
+        block_base = total ? atomicAdd(&a.counts[(size_t)((depth + 1u) * SEGMENTS + seg) * COUNTER_STRIDE], total) : 0u;
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t off = block_base;
+        for (uint32_t w = 0; w < wave; ++w) off += wave_count[w];
+        const size_t out = (size_t)seg * a.seg_cap + off + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
+        Qn[0 * H + out] = __builtin_bit_cast(float, pid);
+        Qn[1 * H + out] = org.x;
+        Qn[2 * H + out] = org.y;
+        Qn[3 * H + out] = org.z;
+        Qn[4 * H + out] = dir.x;
+        Qn[5 * H + out] = dir.y;
+        Qn[6 * H + out] = dir.z;
+        Qn[7 * H + out] = beta.x;
+        Qn[8 * H + out] = beta.y;
+        Qn[9 * H + out] = beta.z;
+        Qn[10 * H + out] = ray_depth;
     }
 }
 
@@ -307,7 +408,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *
         for (uint32_t s = 0; s < a.samples; ++s) {
             const size_t pid = block_base + (size_t)s * PIXEL_BLOCK;
             const float w = 1.0f;
-            const float col[3] = {S[9 * P + pid], S[10 * P + pid], S[11 * P + pid]};
+            const float col[3] = {S[0 * P + pid], S[1 * P + pid], S[2 * P + pid]};
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 acc[ch] += col[ch];
@@ -316,9 +417,9 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *
             }
             acc[9] += w;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc[10 + k] = acc[10 + k] + S[(size_t)(12 + k) * P + pid];
-            acc[19] += S[21 * P + pid];
-            acc[20] += S[22 * P + pid];
+            for (int k = 0; k < 9; ++k) acc[10 + k] = acc[10 + k] + S[(size_t)(3 + k) * P + pid];
+            acc[19] += S[12 * P + pid];
+            acc[20] += S[13 * P + pid];
             acc[21] += count_inc;
             // crates/rt-cli/src/executor.rs:244-249: the pixel is done for this batch once all channels are precise
             if (a.allowed_error > 0.0f && channel_precise(acc[21], acc[0], acc[3], a.allowed_error) &&
@@ -395,10 +496,24 @@ int launch_intersect(const SceneView &scene, const RayAoS *d_rays, HitAoS *d_hit
     return check_launch();
 }
 
-int launch_bounce(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream) {
+int launch_extend(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bounce_kernel, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
+    hipLaunchKernelGGL(extend_kernel, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
     return check_launch();
+}
+
+int launch_shade(const RenderArgs &args, uint32_t depth, uint32_t max_segment_entries, void *stream) {
+    if (max_segment_entries == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t per_seg = (max_segment_entries + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(shade_kernel, dim3(per_seg * SEGMENTS), dim3(BLOCK), 0, s, args, depth);
+    return check_launch();
+}
+
+int extend_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, extend_kernel, BLOCK, 0) != hipSuccess || n < 1) n = 1;
+    return n;
 }
 
 int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, void *stream) {

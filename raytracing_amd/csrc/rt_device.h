@@ -484,19 +484,17 @@ struct Closest {
     uint32_t gidx; // global primitive index of the best candidate, RT_EMPTY = none
     uint32_t slot; // 2 * its record slot + its place in the record
     float u, v;
-    V3 ng; // spheres only
 };
 
 // Candidate order: smaller t wins, equal t goes to the smaller global primitive index, so the result is the same
 // for every traversal order.
-RT_DEV void take_candidate(float t, uint32_t gidx, uint32_t slot, float u, float v, V3 ng, bool ok, Closest &best) {
+RT_DEV void take_candidate(float t, uint32_t gidx, uint32_t slot, float u, float v, bool ok, Closest &best) {
     if (ok && (t < best.t || (t == best.t && gidx < best.gidx))) {
         best.t = t;
         best.gidx = gidx;
         best.slot = slot;
         best.u = u;
         best.v = v;
-        best.ng = ng;
     }
 }
 
@@ -535,6 +533,26 @@ RT_DEV void record_corners(F4 r0, F4 r1, F4 r2, uint32_t code, uint32_t which, V
     }
 }
 
+// Embree's sphere-point formulation: project the centre on the ray, compare the perpendicular distance with the
+// radius; Ng = hit - centre = -+td * d - perp.  False when the ray's line misses the sphere.
+RT_DEV bool sphere_roots(V3 centre, float radius, V3 o, V3 d, float &t_front, float &t_back, V3 &ng_front, V3 &ng_back) {
+    float rd2 = 1.0f / dot(d, d);
+    V3 c0 = sub(centre, o);
+    float proj = dot(c0, d) * rd2;
+    V3 perp = sub(c0, scale(proj, d));
+    float l2 = dot(perp, perp);
+    float r2s = radius * radius;
+    t_front = t_back = 0.0f;
+    ng_front = ng_back = mk(0.0f, 0.0f, 0.0f);
+    if (!(l2 <= r2s)) return false;
+    float td = sqrtf((r2s - l2) * rd2);
+    t_front = proj - td;
+    t_back = proj + td;
+    ng_front = sub(scale(-td, d), perp);
+    ng_back = sub(scale(td, d), perp);
+    return true;
+}
+
 // Tests every primitive of one record.  Closest::slot = 2 * record slot + triangle.
 RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnear, Closest &best) {
     const F4 *p = sv.prims + (size_t)slot * RT_PRIM_F4;
@@ -542,32 +560,17 @@ RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnea
     const uint32_t gidx0 = __builtin_bit_cast(uint32_t, r3.x), gidx1 = __builtin_bit_cast(uint32_t, r3.y);
     const uint32_t code = __builtin_bit_cast(uint32_t, r3.z);
     if (code & RT_SPHERE) {
-        // Embree's sphere-point formulation: project the centre on the ray, compare the perpendicular distance
-        // with the radius; Ng = hit - centre = -+td * d - perp.
-        V3 centre = mk(r0.x, r0.y, r0.z);
-        float radius = r0.w;
-        float rd2 = 1.0f / dot(d, d);
-        V3 c0 = sub(centre, o);
-        float proj = dot(c0, d) * rd2;
-        V3 perp = sub(c0, scale(proj, d));
-        float l2 = dot(perp, perp);
-        float r2s = radius * radius;
-        if (!(l2 <= r2s)) return;
-        float td = sqrtf((r2s - l2) * rd2);
-        float t_front = proj - td;
-        float t_back = proj + td;
+        float t_front, t_back;
+        V3 ng_front, ng_back;
+        if (!sphere_roots(mk(r0.x, r0.y, r0.z), r0.w, o, d, t_front, t_back, ng_front, ng_back)) return;
         float t;
-        V3 ng;
-        if (tnear <= t_front && t_front <= best.t) {
+        if (tnear <= t_front && t_front <= best.t)
             t = t_front;
-            ng = sub(scale(-td, d), perp);
-        } else if (tnear <= t_back && t_back <= best.t) {
+        else if (tnear <= t_back && t_back <= best.t)
             t = t_back;
-            ng = sub(scale(td, d), perp);
-        } else {
+        else
             return;
-        }
-        take_candidate(t, gidx0, 2u * slot, 0.0f, 0.0f, ng, true, best);
+        take_candidate(t, gidx0, 2u * slot, 0.0f, 0.0f, true, best);
         return;
     }
     V3 a0, a1, a2, b0, b1, b2;
@@ -576,9 +579,27 @@ RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnea
     float ta, ua, va, tb, ub, vb;
     const bool oka = tri_test(a0, sub(a1, a0), sub(a2, a0), o, d, tnear, ta, ua, va);
     const bool okb = tri_test(b0, sub(b1, b0), sub(b2, b0), o, d, tnear, tb, ub, vb) && gidx1 != RT_EMPTY;
-    const V3 zero = mk(0.0f, 0.0f, 0.0f);
-    take_candidate(ta, gidx0, 2u * slot, ua, va, zero, oka, best);
-    take_candidate(tb, gidx1, 2u * slot + 1u, ub, vb, zero, okb, best);
+    take_candidate(ta, gidx0, 2u * slot, ua, va, oka, best);
+    take_candidate(tb, gidx1, 2u * slot + 1u, ub, vb, okb, best);
+}
+
+// Geometric normal (not normalised) of the accepted candidate, the word holding its geometry id and the global index
+// of the first primitive of that geometry.  A sphere's roots are evaluated again: the same operations on the same
+// operands give the same bits as during the test, and the front root is the one taken when both equal t.
+RT_DEV V3 candidate_normal(const SceneView &sv, uint32_t slot2, V3 o, V3 d, float t, uint32_t &code, uint32_t &geom_first) {
+    const F4 *p = sv.prims + (size_t)(slot2 >> 1) * RT_PRIM_F4;
+    F4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+    code = __builtin_bit_cast(uint32_t, r3.z);
+    geom_first = __builtin_bit_cast(uint32_t, r3.w);
+    if (code & RT_SPHERE) {
+        float t_front, t_back;
+        V3 ng_front, ng_back;
+        sphere_roots(mk(r0.x, r0.y, r0.z), r0.w, o, d, t_front, t_back, ng_front, ng_back);
+        return t == t_front ? ng_front : ng_back;
+    }
+    V3 v0, v1, v2;
+    record_corners(r0, r1, r2, code, slot2 & 1u, v0, v1, v2);
+    return cross(sub(v1, v0), sub(v2, v0));
 }
 
 // Reciprocal that never produces inf, so that 0 * inv is 0 and not NaN in the slab test.
@@ -599,7 +620,6 @@ RT_DEV void trav_begin(const SceneView &sv, V3 o, V3 d, float tfar, Trav &tr) {
     tr.best.gidx = RT_EMPTY;
     tr.best.slot = 0;
     tr.best.u = tr.best.v = 0.0f;
-    tr.best.ng = mk(0.0f, 0.0f, 0.0f);
     tr.ix = safe_rcp(d.x);
     tr.iy = safe_rcp(d.y);
     tr.iz = safe_rcp(d.z);
@@ -726,15 +746,8 @@ RT_DEV void finish_hit(const SceneView &sv, V3 o, V3 d, const Closest &best, Hit
         h.mat_id = 0;
         return;
     }
-    const F4 *p = sv.prims + (size_t)(best.slot >> 1) * RT_PRIM_F4;
-    F4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
-    const uint32_t code = __builtin_bit_cast(uint32_t, r3.z);
-    V3 ng = best.ng;
-    if (!(code & RT_SPHERE)) {
-        V3 v0, v1, v2;
-        record_corners(r0, r1, r2, code, best.slot & 1u, v0, v1, v2);
-        ng = cross(sub(v1, v0), sub(v2, v0));
-    }
+    uint32_t code, geom_first;
+    const V3 ng = candidate_normal(sv, best.slot, o, d, best.t, code, geom_first);
     h.hit = true;
     h.t = best.t;
     h.pos = mk(o.x + best.t * d.x, o.y + best.t * d.y, o.z + best.t * d.z);
@@ -742,7 +755,7 @@ RT_DEV void finish_hit(const SceneView &sv, V3 o, V3 d, const Closest &best, Hit
     h.u = best.u;
     h.v = best.v;
     h.geom_id = code & RT_GEOM_MASK;
-    h.prim_id = best.gidx - __builtin_bit_cast(uint32_t, r3.w);
+    h.prim_id = best.gidx - geom_first;
     h.mat_id = h.geom_id < sv.n_geoms ? sv.geom_material[h.geom_id] : 0u;
     if (h.mat_id >= sv.n_materials) h.mat_id = 0u;
 }

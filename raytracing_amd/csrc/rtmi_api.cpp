@@ -73,7 +73,8 @@ struct rtmi_film {
     // workspace, grown on demand
     size_t cap_paths = 0;
     float *d_state = nullptr;
-    uint32_t *d_queue[2] = {nullptr, nullptr};
+    float *d_hits = nullptr;
+    float *d_queue[2] = {nullptr, nullptr}; // ray payload planes, ping-pong by bounce parity
     size_t cap_counters = 0;
     uint32_t *d_counts = nullptr; // counts + work, cap_counters entries each
     float *d_resolve = nullptr;
@@ -325,11 +326,9 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
     HIP_TRY(hipMalloc((void **)&scene->d_materials, scene->materials.size() * sizeof(rtd::Material)));
     HIP_TRY(hipMemcpy(scene->d_materials, scene->materials.data(), scene->materials.size() * sizeof(rtd::Material),
                       hipMemcpyHostToDevice));
-    // resident grid: LDS (LDS_STACK * BLOCK * 4 bytes per block of 160 KiB) and 8 blocks of 4 waves per CU at most
+    // resident grid of the traversal kernel (its LDS stack and registers bound the blocks per CU)
     {
-        const uint32_t lds_per_block = rtk::LDS_STACK * rtk::BLOCK * 4u;
-        const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (160u * 1024u) / lds_per_block));
-        scene->grid_blocks = (uint32_t)dev->n_cu * per_cu;
+        scene->grid_blocks = (uint32_t)dev->n_cu * (uint32_t)rtk::extend_blocks_per_cu();
         const size_t deep = bvh.stack_need > (uint32_t)rtk::LDS_STACK ? bvh.stack_need - rtk::LDS_STACK : 0;
         const size_t spill_bytes = std::max<size_t>(16, deep * scene->grid_blocks * rtk::BLOCK * sizeof(uint32_t));
         HIP_TRY(hipMalloc((void **)&scene->d_spill, spill_bytes));
@@ -461,6 +460,7 @@ void rtmi_film_destroy(rtmi_film *film) {
     if (film->d_xy) (void)hipFree(film->d_xy);
     if (film->own_accum && film->d_accum) (void)hipFree(film->d_accum);
     if (film->d_state) (void)hipFree(film->d_state);
+    if (film->d_hits) (void)hipFree(film->d_hits);
     if (film->d_queue[0]) (void)hipFree(film->d_queue[0]);
     if (film->d_queue[1]) (void)hipFree(film->d_queue[1]);
     if (film->d_counts) (void)hipFree(film->d_counts);
@@ -525,15 +525,15 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     hipStream_t stream = dev->stream;
 
     // samples traced together per pass
-    // Default: as many samples of every pixel in flight as fit a quarter of the free HBM (100 bytes of state per
-    // path), so that the long, thin tail of deep bounces is paid once per frame and not once per small pass.
+    // Default: as many samples of every pixel in flight as fit a quarter of the free HBM (164 bytes of state, hit
+    // record and two queue entries per path), so that the long, thin tail of deep bounces is paid once per frame and not once per small pass.
     uint32_t spp_pass = params->samples_per_pass;
     if (spp_pass == 0) {
         size_t free_b = 0, total_b = 0;
         size_t target_paths = (size_t)8 << 20;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            size_t have = film->cap_paths * (rtk::STATE_PLANES * sizeof(float) + 2 * sizeof(uint32_t));
-            target_paths = std::max(target_paths, (free_b + have) / 4 / 100);
+            const size_t per_path = (rtk::STATE_PLANES + rtk::HIT_PLANES + 2 * rtk::PAYLOAD_PLANES) * sizeof(float);
+            target_paths = std::max(target_paths, (free_b + film->cap_paths * per_path) / 4 / per_path);
         }
         target_paths = std::min<size_t>(target_paths, (size_t)1 << 28);
         spp_pass = (uint32_t)std::max<size_t>(1, target_paths / npix);
@@ -554,14 +554,16 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
 
     if (film->cap_paths < max_paths) {
         if (film->d_state) (void)hipFree(film->d_state);
+        if (film->d_hits) (void)hipFree(film->d_hits);
         if (film->d_queue[0]) (void)hipFree(film->d_queue[0]);
         if (film->d_queue[1]) (void)hipFree(film->d_queue[1]);
-        film->d_state = nullptr;
+        film->d_state = film->d_hits = nullptr;
         film->d_queue[0] = film->d_queue[1] = nullptr;
         film->cap_paths = 0;
         HIP_TRY(hipMalloc((void **)&film->d_state, max_paths * rtk::STATE_PLANES * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&film->d_queue[0], max_paths * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&film->d_queue[1], max_paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&film->d_hits, max_paths * rtk::HIT_PLANES * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&film->d_queue[0], max_paths * rtk::PAYLOAD_PLANES * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&film->d_queue[1], max_paths * rtk::PAYLOAD_PLANES * sizeof(float)));
         film->cap_paths = max_paths;
     }
     if (film->cap_counters < n_counters) {
@@ -587,8 +589,9 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     memcpy(a.camera.rot, camera->rot, 16);
     a.pixels = film->d_xy;
     a.state = film->d_state;
-    a.queue[0] = film->d_queue[0];
-    a.queue[1] = film->d_queue[1];
+    a.hits = film->d_hits;
+    a.payload[0] = film->d_queue[0];
+    a.payload[1] = film->d_queue[1];
     a.visit_counters = dev->count_visits ? dev->d_visits : nullptr;
     a.n_pixels = (uint32_t)npix;
     a.n_blocks = (uint32_t)n_blocks;
@@ -599,7 +602,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.seed = params->seed;
 
     a.allowed_error = (params->allowed_error > 0.0f) ? params->allowed_error : 0.0f;
-    a.refill_below = 32;
+    a.refill_below = 48;
     a.leaf_bias = 0;
     if (const char *v = getenv("RTMI_REFILL_BELOW")) a.refill_below = atoi(v);
     if (const char *v = getenv("RTMI_LEAF_BIAS")) a.leaf_bias = atoi(v);
@@ -632,6 +635,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         }
         (void)hipEventRecord(ev_pass[2 * pass], stream);
         uint64_t live = (uint64_t)k * npix; // rays entering the bounce about to be launched
+        uint32_t longest = a.seg_cap;       // entries of the longest segment at that bounce
         paths += live;
         for (uint32_t depth = 0; depth < params->max_depth && live > 0; ++depth) {
             rays += live;
@@ -643,7 +647,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full_grid, want_blocks));
             const uint64_t per_wave = entries / ((uint64_t)grid * waves_per_block * rtk::SEGMENTS) / 8;
             a.claim = 64u * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, per_wave / 64));
-            if (rtk::launch_bounce(a, depth, grid, stream)) {
+            if (rtk::launch_extend(a, depth, grid, stream) || rtk::launch_shade(a, depth, longest, stream)) {
                 rc = fail(RTMI_ERR_DEVICE, "bounce kernel launch failed");
                 break;
             }
@@ -658,7 +662,11 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
                 break;
             }
             live = 0;
-            for (int x = 0; x < rtk::SEGMENTS; ++x) live += h_counts[(size_t)x * rtk::COUNTER_STRIDE];
+            longest = 0;
+            for (int x = 0; x < rtk::SEGMENTS; ++x) {
+                live += h_counts[(size_t)x * rtk::COUNTER_STRIDE];
+                longest = std::max(longest, h_counts[(size_t)x * rtk::COUNTER_STRIDE]);
+            }
         }
         (void)hipEventRecord(ev_pass[2 * pass + 1], stream);
         if (rc == RTMI_OK && rtk::launch_accumulate(a, film->d_accum, 1.0f, stream))
