@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtmi.so")
+LIB_PATH = os.environ.get("RTMI_LIB") or os.path.join(_HERE, "librtmi.so")  # RTMI_LIB: an alternative build of the same library
 
 ACCUM_PLANES = 22
 RESOLVE_PLANES = 15

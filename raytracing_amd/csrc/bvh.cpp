@@ -260,8 +260,8 @@ bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool
             org[a] = isfinite(u.lo[a]) ? u.lo[a] : 0.0f;
             const double ext = (double)u.hi[a] - (double)org[a];
             int e = -100;
-            if (!(ext <= 1e30)) // non-finite or huge
-                e = 100;
+            if (!(ext <= 1e14)) // non-finite or huge: such boxes are not representable (and not supported)
+                e = 40;
             else if (ext > 0.0) {
                 e = (int)ceil(log2(ext / 255.0));
                 if (ldexp(255.0, e) < ext) ++e;

@@ -21,31 +21,43 @@ namespace rtk {
 // Per-lane traversal stack: the first LDS_STACK entries live in LDS, deeper ones (rare: the tree's worst case is far
 // above the typical depth) spill to a per-thread column of a global buffer sized from the committed tree.
 struct LaneStack {
-    uint32_t *col;  // &lds[thread of block]; entry e is at col[e * BLOCK]
-    uint32_t *ovf;  // &spill[global thread]; entry LDS_STACK + e is at ovf[e * ovf_stride]
-    size_t ovf_stride;
+    uint32_t *col;   // &lds[thread of block]; entry e is at col[e * BLOCK]
+    uint32_t *spill; // wave-uniform base; entry LDS_STACK + e of a thread is at spill[e * threads + global thread]
     int sp;
+    bool shallow; // wave-uniform: no lane of the wave is within 4 entries of the LDS part's end (see note_depth)
+    __device__ __forceinline__ uint32_t *deep(int e) const {
+        const size_t threads = (size_t)gridDim.x * BLOCK;
+        return spill + (size_t)(e - LDS_STACK) * threads + ((size_t)blockIdx.x * BLOCK + threadIdx.x);
+    }
     __device__ __forceinline__ void push(uint32_t v) {
-        if (sp < LDS_STACK)
+        if (shallow || sp < LDS_STACK)
             col[sp * BLOCK] = v;
         else
-            ovf[(size_t)(sp - LDS_STACK) * ovf_stride] = v;
+            *deep(sp) = v;
         ++sp;
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
-        return sp < LDS_STACK ? col[sp * BLOCK] : ovf[(size_t)(sp - LDS_STACK) * ovf_stride];
+        return (shallow || sp < LDS_STACK) ? col[sp * BLOCK] : *deep(sp);
     }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
+    // Call with all lanes of the wave active, before a step that pushes at most three entries: the common case of a
+    // shallow stack then skips the per-lane spill checks.
+    __device__ __forceinline__ void note_depth() { shallow = __ballot(sp > LDS_STACK - 4) == 0ull; }
 };
 
 __device__ __forceinline__ LaneStack make_stack(uint32_t *lds, uint32_t *spill) {
     LaneStack st;
     st.col = lds + threadIdx.x;
-    st.ovf_stride = (size_t)gridDim.x * BLOCK;
-    st.ovf = spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    st.spill = spill;
     st.sp = 0;
+    st.shallow = false;
     return st;
+}
+
+// Number of set bits of a wave mask below this lane.
+__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const RayAoS *__restrict__ rays,
@@ -79,6 +91,14 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const
         hp[1] = h1;
         hp[2] = h2;
     }
+}
+
+// Element idx of a plane: uniform plane base + 32-bit byte offset (a plane is at most 4 GiB).
+__device__ __forceinline__ float ldp(const float *plane, uint32_t idx) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(plane) + (idx << 2));
+}
+__device__ __forceinline__ void stp(float *plane, uint32_t idx, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(plane) + (idx << 2)) = v;
 }
 
 // XCC_ID hardware register (bits 3:0): the XCD this wave runs on.  Used for locality only, never for correctness.
@@ -121,6 +141,26 @@ __device__ __forceinline__ uint32_t segment_entries(const RenderArgs &a, uint32_
     return a.counts[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE];
 }
 
+// Camera rays of every path of a pass, in the implicit queue order of bounce 0, into the bounce's payload planes.
+// Padding entries (pixels past n_pixels) get a zero direction, which no camera ray has.
+__global__ __launch_bounds__(BLOCK) void raygen_kernel(RenderArgs a) {
+    const uint32_t seg = blockIdx.x % (uint32_t)SEGMENTS;
+    const uint32_t i = (blockIdx.x / (uint32_t)SEGMENTS) * (uint32_t)BLOCK + threadIdx.x;
+    if (i >= segment_entries(a, 0u, seg)) return;
+    const size_t H = (size_t)SEGMENTS * a.seg_cap;
+    float *__restrict__ Q = a.payload[0];
+    const uint32_t pos = seg * a.seg_cap + i;
+    const Entry e = queue_entry(a, 0u, seg, i, nullptr);
+    V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 0.0f);
+    if (e.valid) camera_ray(a.camera, a.strata, a.seed, a.pixels[2 * e.pix], a.pixels[2 * e.pix + 1], e.sample, org, dir);
+    stp(Q + 1 * H, pos, org.x);
+    stp(Q + 2 * H, pos, org.y);
+    stp(Q + 3 * H, pos, org.z);
+    stp(Q + 4 * H, pos, dir.x);
+    stp(Q + 5 * H, pos, dir.y);
+    stp(Q + 6 * H, pos, dir.z);
+}
+
 // Closest hit of every ray of one bounce.  Waves are persistent: a lane whose ray has finished writes its hit record
 // and takes the next queue entry while the other lanes of the wave keep their rays, so the traversal loop runs with
 // most lanes busy.  Finished lanes are flushed and refilled in batches (when fewer than RenderArgs::refill_below lanes
@@ -128,132 +168,122 @@ __device__ __forceinline__ uint32_t segment_entries(const RenderArgs &a, uint32_
 // or primitive test -- that most of its busy lanes are waiting for.
 //
 // Hit record of queue entry i of segment x, at plane offset x * seg_cap + i: distance (+inf = miss), geometric normal
-// (not normalised), geometry word.  Rays come from the bounce's payload planes, in queue order; at bounce 0 the camera
-// ray is generated here and stored there for the shading kernel.
-__global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t depth) {
+// (not normalised), geometry word.  Rays come from the bounce's payload planes, in queue order.
+//
+// PRIMARY: bounce 0, whose queue has padding entries (zero direction) that are skipped.  COUNT: tally node visits and
+// primitive tests.
+template <bool PRIMARY, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t depth_arg) {
     __shared__ uint32_t lds[LDS_STACK * BLOCK];
     LaneStack st = make_stack(lds, a.spill);
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t depth = PRIMARY ? 0u : depth_arg;
     const size_t H = (size_t)SEGMENTS * a.seg_cap;
     float *__restrict__ hits = a.hits;
-    float *__restrict__ Q = a.payload[depth & 1u]; // this bounce's rays, in queue order
+    const float *__restrict__ Q = a.payload[depth & 1u]; // this bounce's rays, in queue order
     uint32_t nodes = 0, tests = 0;
-    const bool count_visits = a.visit_counters != nullptr;
     const uint32_t home = xcd_of_wave();
 
-    for (uint32_t turn = 0; turn < (uint32_t)SEGMENTS; ++turn) {
-        const uint32_t seg = (home + turn) & (uint32_t)(SEGMENTS - 1);
-        const uint32_t n_in = segment_entries(a, depth, seg);
-        uint32_t *cursor = &a.work[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE];
-        uint32_t c_next = 0, c_end = 0; // wave-uniform: the part of the queue this wave has claimed and not yet used
-        bool drained = n_in == 0u;      // wave-uniform: the segment has no unclaimed entries left
+    // wave-uniform: the segment being drained and the part of its queue this wave has claimed and not yet used
+    uint32_t turn = 0, seg = home;
+    uint32_t n_in = segment_entries(a, depth, seg);
+    uint32_t c_next = 0, c_end = 0;
+    bool drained = n_in == 0u; // the segment has no unclaimed entries left
 
-        bool has_ray = false;
-        uint32_t slot_out = 0; // where this lane's hit record goes
-        V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f);
-        Trav tr;
-        tr.cur = RT_EMPTY;
+    bool has_ray = false;
+    uint32_t slot_out = 0; // where this lane's hit record goes
+    V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f);
+    Trav tr;
+    tr.cur = RT_EMPTY;
 
-        for (;;) {
-            const bool busy = has_ray && tr.cur != RT_EMPTY;
-            const int n_busy = (int)__popcll(__ballot(busy));
-            bool more = !drained || c_next != c_end;
-            if (n_busy == 0 || n_busy < a.refill_below) {
-                // ---- flush the finished lanes
-                if (has_ray && !busy) {
-                    float t = INFINITY;
-                    V3 ng = mk(0.0f, 0.0f, 0.0f);
-                    uint32_t code = RT_EMPTY, geom_first;
-                    if (tr.best.gidx != RT_EMPTY) {
-                        t = tr.best.t;
-                        ng = candidate_normal(a.scene, tr.best.slot, org, dir, t, code, geom_first);
-                    }
-                    hits[0 * H + slot_out] = t;
-                    hits[1 * H + slot_out] = ng.x;
-                    hits[2 * H + slot_out] = ng.y;
-                    hits[3 * H + slot_out] = ng.z;
-                    hits[4 * H + slot_out] = __builtin_bit_cast(float, code);
-                    has_ray = false;
+    for (;;) {
+        const bool busy = has_ray && tr.cur != RT_EMPTY;
+        const int n_busy = (int)__popcll(__ballot(busy));
+        if (n_busy < a.refill_below) {
+            // ---- flush the finished lanes
+            if (has_ray && !busy) {
+                float t = INFINITY;
+                V3 ng = mk(0.0f, 0.0f, 0.0f);
+                uint32_t code = RT_EMPTY, geom_first;
+                if (tr.best.gidx != RT_EMPTY) {
+                    t = tr.best.t;
+                    ng = candidate_normal(a.scene, tr.best.slot, org, dir, t, code, geom_first);
                 }
-                // ---- refill idle lanes from the wave's claimed range; claim the next a.claim entries with one
-                // atomic when the range is used up
-                if (c_next == c_end && !drained) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(cursor, a.claim);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= n_in) {
-                        drained = true;
-                    } else {
-                        c_next = base;
-                        c_end = min(base + a.claim, n_in);
-                        if (c_end == n_in) drained = true;
-                    }
-                }
-                if (c_next != c_end) {
-                    const unsigned long long nmask = __ballot(!has_ray);
-                    const uint32_t i = c_next + (uint32_t)__popcll(nmask & below);
-                    const bool take = !has_ray && i < c_end;
-                    c_next = min(c_end, c_next + (uint32_t)__popcll(nmask));
-                    if (take) {
-                        const size_t pos = (size_t)seg * a.seg_cap + i;
-                        bool valid = true;
-                        if (depth == 0u) {
-                            const Entry e = queue_entry(a, depth, seg, i, nullptr);
-                            valid = e.valid;
-                            if (valid) {
-                                camera_ray(a.camera, a.strata, a.seed, a.pixels[2 * e.pix], a.pixels[2 * e.pix + 1], e.sample,
-                                           org, dir);
-                                Q[1 * H + pos] = org.x;
-                                Q[2 * H + pos] = org.y;
-                                Q[3 * H + pos] = org.z;
-                                Q[4 * H + pos] = dir.x;
-                                Q[5 * H + pos] = dir.y;
-                                Q[6 * H + pos] = dir.z;
-                            }
-                        } else {
-                            org = mk(Q[1 * H + pos], Q[2 * H + pos], Q[3 * H + pos]);
-                            dir = mk(Q[4 * H + pos], Q[5 * H + pos], Q[6 * H + pos]);
-                        }
-                        if (valid) {
-                            slot_out = (uint32_t)pos;
-                            st.sp = 0;
-                            trav_begin(a.scene, org, dir, INFINITY, tr);
-                            has_ray = true;
-                        }
-                    }
-                }
-                more = !drained || c_next != c_end;
-                if (__ballot(has_ray) == 0ull) {
-                    if (!more) break;
-                    continue; // only padding entries were taken: take more
+                stp(hits + 0 * H, slot_out, t);
+                stp(hits + 1 * H, slot_out, ng.x);
+                stp(hits + 2 * H, slot_out, ng.y);
+                stp(hits + 3 * H, slot_out, ng.z);
+                stp(hits + 4 * H, slot_out, __builtin_bit_cast(float, code));
+                has_ray = false;
+            }
+            // ---- move on to the next segment once this one is used up; claim the next a.claim entries with one atomic
+            // when the wave's range is used up
+            while (c_next == c_end && drained && turn + 1u < (uint32_t)SEGMENTS) {
+                ++turn;
+                seg = (home + turn) & (uint32_t)(SEGMENTS - 1);
+                n_in = segment_entries(a, depth, seg);
+                drained = n_in == 0u;
+            }
+            if (c_next == c_end && !drained) {
+                uint32_t base = 0;
+                if (rank_in(~0ull) == 0u) base = atomicAdd(&a.work[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE], a.claim);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n_in) {
+                    drained = true;
+                } else {
+                    c_next = base;
+                    c_end = min(base + a.claim, n_in);
+                    if (c_end == n_in) drained = true;
                 }
             }
-            // ---- one traversal step
-            const bool at_leaf = has_ray && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
-            const bool at_node = has_ray && tr.cur != RT_EMPTY && !at_leaf;
-            const int n_node = (int)__popcll(__ballot(at_node));
-            const int n_leaf = (int)__popcll(__ballot(at_leaf));
-            if (n_leaf == 0 || (n_node > 0 && n_node >= n_leaf + a.leaf_bias)) {
-                if (at_node) {
-                    if (count_visits) ++nodes;
-                    trav_node_step(a.scene, RT_TNEAR, tr, st);
+            // ---- refill idle lanes from the claimed range
+            if (c_next != c_end) {
+                const unsigned long long nmask = __ballot(!has_ray);
+                const uint32_t i = c_next + rank_in(nmask);
+                const bool take = !has_ray && i < c_end;
+                c_next = min(c_end, c_next + (uint32_t)__popcll(nmask));
+                if (take) {
+                    const uint32_t pos = seg * a.seg_cap + i;
+                    org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+                    dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
+                    if (!PRIMARY || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
+                        slot_out = pos;
+                        st.sp = 0;
+                        trav_begin(a.scene, org, dir, INFINITY, tr);
+                        has_ray = true;
+                    }
                 }
-            } else {
-                if (at_leaf) {
-                    if (count_visits) ++tests;
-                    trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
-                }
+            }
+            if (__ballot(has_ray) == 0ull) {
+                // nothing in flight: done when every segment is used up, otherwise take more
+                if (c_next == c_end && drained && turn + 1u >= (uint32_t)SEGMENTS) break;
+                continue;
+            }
+        }
+        // ---- one traversal step
+        st.note_depth();
+        const bool at_leaf = has_ray && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
+        const bool at_node = has_ray && tr.cur != RT_EMPTY && !at_leaf;
+        const int n_node = (int)__popcll(__ballot(at_node));
+        const int n_leaf = (int)__popcll(__ballot(at_leaf));
+        if (n_leaf == 0 || (n_node > 0 && n_node >= n_leaf + a.leaf_bias)) {
+            if (at_node) {
+                if (COUNT) ++nodes;
+                trav_node_step(a.scene, RT_TNEAR, tr, st);
+            }
+        } else {
+            if (at_leaf) {
+                if (COUNT) ++tests;
+                trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
             }
         }
     }
-    if (count_visits) {
+    if (COUNT) {
         // wave-level sums, then one 64-bit atomic pair per wave
         for (int off = 32; off > 0; off >>= 1) {
             nodes += __shfl_down(nodes, off);
             tests += __shfl_down(tests, off);
         }
-        if (lane == 0) {
+        if (rank_in(~0ull) == 0u) {
             atomicAdd(reinterpret_cast<unsigned long long *>(a.visit_counters), (unsigned long long)nodes);
             atomicAdd(reinterpret_cast<unsigned long long *>(a.visit_counters) + 1, (unsigned long long)tests);
         }
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
     const float *__restrict__ hits = a.hits;
     const float *__restrict__ Q = a.payload[depth & 1u];
     float *__restrict__ Qn = a.payload[(depth + 1u) & 1u];
-    const size_t pos = (size_t)seg * a.seg_cap + i;
+    const uint32_t pos = seg * a.seg_cap + i;
 
     bool alive = false;
     uint32_t pid = 0;
@@ -286,14 +316,14 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
         const Entry e = queue_entry(a, depth, seg, i, Q + (size_t)seg * a.seg_cap);
         pid = e.pid;
         if (e.valid) {
-            org = mk(Q[1 * H + pos], Q[2 * H + pos], Q[3 * H + pos]);
-            dir = mk(Q[4 * H + pos], Q[5 * H + pos], Q[6 * H + pos]);
+            org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+            dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
             beta = mk(1.0f, 1.0f, 1.0f);
             if (depth != 0u) {
-                beta = mk(Q[7 * H + pos], Q[8 * H + pos], Q[9 * H + pos]);
-                ray_depth = Q[10 * H + pos];
+                beta = mk(ldp(Q + 7 * H, pos), ldp(Q + 8 * H, pos), ldp(Q + 9 * H, pos));
+                ray_depth = ldp(Q + 10 * H, pos);
             }
-            const uint32_t code = __builtin_bit_cast(uint32_t, hits[4 * H + pos]);
+            const uint32_t code = __builtin_bit_cast(uint32_t, ldp(hits + 4 * H, pos));
             HitInfo h;
             h.u = h.v = 0.0f;
             h.prim_id = RT_EMPTY;
@@ -306,9 +336,9 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
                 h.mat_id = 0;
             } else {
                 h.hit = true;
-                h.t = hits[0 * H + pos];
+                h.t = ldp(hits + 0 * H, pos);
                 h.pos = mk(org.x + h.t * dir.x, org.y + h.t * dir.y, org.z + h.t * dir.z);
-                h.n = normalize_or_zero(mk(hits[1 * H + pos], hits[2 * H + pos], hits[3 * H + pos]));
+                h.n = normalize_or_zero(mk(ldp(hits + 1 * H, pos), ldp(hits + 2 * H, pos), ldp(hits + 3 * H, pos)));
                 h.geom_id = code & RT_GEOM_MASK;
                 h.mat_id = h.geom_id < a.scene.n_geoms ? a.scene.geom_material[h.geom_id] : 0u;
                 if (h.mat_id >= a.scene.n_materials) h.mat_id = 0u;
@@ -317,16 +347,16 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
             bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, a.pixels[2 * e.pix], a.pixels[2 * e.pix + 1], e.sample,
                                      depth, org, dir, beta, vo);
             if (depth == 0u) {
-                S[3 * P + pid] = vo.normal.x;
-                S[4 * P + pid] = vo.normal.y;
-                S[5 * P + pid] = vo.normal.z;
-                S[6 * P + pid] = vo.position.x;
-                S[7 * P + pid] = vo.position.y;
-                S[8 * P + pid] = vo.position.z;
-                S[9 * P + pid] = vo.albedo.x;
-                S[10 * P + pid] = vo.albedo.y;
-                S[11 * P + pid] = vo.albedo.z;
-                S[12 * P + pid] = vo.z;
+                stp(S + 3 * P, pid, vo.normal.x);
+                stp(S + 4 * P, pid, vo.normal.y);
+                stp(S + 5 * P, pid, vo.normal.z);
+                stp(S + 6 * P, pid, vo.position.x);
+                stp(S + 7 * P, pid, vo.position.y);
+                stp(S + 8 * P, pid, vo.position.z);
+                stp(S + 9 * P, pid, vo.albedo.x);
+                stp(S + 10 * P, pid, vo.albedo.y);
+                stp(S + 11 * P, pid, vo.albedo.z);
+                stp(S + 12 * P, pid, vo.z);
                 ray_depth = 0.0f + vo.t_add;
             } else if (h.hit && vo.t_add != 0.0f) {
                 ray_depth = ray_depth + vo.t_add;
@@ -339,10 +369,10 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
             if (cont) {
                 alive = true;
             } else {
-                S[0 * P + pid] = vo.radiance.x;
-                S[1 * P + pid] = vo.radiance.y;
-                S[2 * P + pid] = vo.radiance.z;
-                S[13 * P + pid] = ray_depth;
+                stp(S + 0 * P, pid, vo.radiance.x);
+                stp(S + 1 * P, pid, vo.radiance.y);
+                stp(S + 2 * P, pid, vo.radiance.z);
+                stp(S + 13 * P, pid, ray_depth);
             }
         }
     }
@@ -359,18 +389,18 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
     if (alive) {
         uint32_t off = block_base;
         for (uint32_t w = 0; w < wave; ++w) off += wave_count[w];
-        const size_t out = (size_t)seg * a.seg_cap + off + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
-        Qn[0 * H + out] = __builtin_bit_cast(float, pid);
-        Qn[1 * H + out] = org.x;
-        Qn[2 * H + out] = org.y;
-        Qn[3 * H + out] = org.z;
-        Qn[4 * H + out] = dir.x;
-        Qn[5 * H + out] = dir.y;
-        Qn[6 * H + out] = dir.z;
-        Qn[7 * H + out] = beta.x;
-        Qn[8 * H + out] = beta.y;
-        Qn[9 * H + out] = beta.z;
-        Qn[10 * H + out] = ray_depth;
+        const uint32_t out = seg * a.seg_cap + off + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
+        stp(Qn + 0 * H, out, __builtin_bit_cast(float, pid));
+        stp(Qn + 1 * H, out, org.x);
+        stp(Qn + 2 * H, out, org.y);
+        stp(Qn + 3 * H, out, org.z);
+        stp(Qn + 4 * H, out, dir.x);
+        stp(Qn + 5 * H, out, dir.y);
+        stp(Qn + 6 * H, out, dir.z);
+        stp(Qn + 7 * H, out, beta.x);
+        stp(Qn + 8 * H, out, beta.y);
+        stp(Qn + 9 * H, out, beta.z);
+        stp(Qn + 10 * H, out, ray_depth);
     }
 }
 
@@ -498,7 +528,18 @@ int launch_intersect(const SceneView &scene, const RayAoS *d_rays, HitAoS *d_hit
 
 int launch_extend(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(extend_kernel, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
+    const bool count = args.visit_counters != nullptr;
+    if (depth == 0u) {
+        if (count)
+            hipLaunchKernelGGL((extend_kernel<true, true>), dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
+        else
+            hipLaunchKernelGGL((extend_kernel<true, false>), dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
+    } else {
+        if (count)
+            hipLaunchKernelGGL((extend_kernel<false, true>), dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
+        else
+            hipLaunchKernelGGL((extend_kernel<false, false>), dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
+    }
     return check_launch();
 }
 
@@ -510,9 +551,18 @@ int launch_shade(const RenderArgs &args, uint32_t depth, uint32_t max_segment_en
     return check_launch();
 }
 
+int launch_raygen(const RenderArgs &args, void *stream) {
+    if (args.seg_cap == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t per_seg = (args.seg_cap + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(raygen_kernel, dim3(per_seg * SEGMENTS), dim3(BLOCK), 0, s, args);
+    return check_launch();
+}
+
 int extend_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, extend_kernel, BLOCK, 0) != hipSuccess || n < 1) n = 1;
+    // the widest of the variants sizes the resident grid (and with it the stack spill buffer)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, extend_kernel<false, false>, BLOCK, 0) != hipSuccess || n < 1) n = 1;
     return n;
 }
 

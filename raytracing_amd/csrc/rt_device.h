@@ -74,6 +74,16 @@ struct SceneView {
     uint32_t n_materials;
 };
 
+// Node and record addresses are a uniform base plus a 32-bit byte offset (one shift; the hardware adds the base), which
+// is why a scene is limited to RT_MAX_ITEMS nodes and RT_MAX_ITEMS records.
+constexpr uint32_t RT_MAX_ITEMS = 1u << 26;
+RT_DEV const U4 *node_at(const SceneView &sv, uint32_t node) {
+    return reinterpret_cast<const U4 *>(reinterpret_cast<const char *>(sv.nodes) + (node << 6));
+}
+RT_DEV const F4 *record_at(const SceneView &sv, uint32_t slot) {
+    return reinterpret_cast<const F4 *>(reinterpret_cast<const char *>(sv.prims) + (slot << 6));
+}
+
 struct CameraView {
     uint32_t width, height;
     float half_width, half_height, focal_length, aperture;
@@ -498,8 +508,8 @@ RT_DEV void take_candidate(float t, uint32_t gidx, uint32_t slot, float u, float
     }
 }
 
-// Moeller-Trumbore, no culling; edges inclusive; NaNs reject.  Written without early exits so that the two
-// triangles of a record overlap in the pipeline; every value is the one the exiting form would have computed.
+// Moeller-Trumbore, no culling; edges inclusive; NaNs reject.  Written without early exits (lanes of a wave rarely
+// agree on them); every value is the one the exiting form would have computed.
 RT_DEV bool tri_test(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float tnear, float &t, float &u, float &v) {
     V3 pv = cross(d, e2);
     float det = dot(e1, pv);
@@ -555,7 +565,7 @@ RT_DEV bool sphere_roots(V3 centre, float radius, V3 o, V3 d, float &t_front, fl
 
 // Tests every primitive of one record.  Closest::slot = 2 * record slot + triangle.
 RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnear, Closest &best) {
-    const F4 *p = sv.prims + (size_t)slot * RT_PRIM_F4;
+    const F4 *p = record_at(sv, slot);
     F4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
     const uint32_t gidx0 = __builtin_bit_cast(uint32_t, r3.x), gidx1 = __builtin_bit_cast(uint32_t, r3.y);
     const uint32_t code = __builtin_bit_cast(uint32_t, r3.z);
@@ -573,21 +583,32 @@ RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnea
         take_candidate(t, gidx0, 2u * slot, 0.0f, 0.0f, true, best);
         return;
     }
-    V3 a0, a1, a2, b0, b1, b2;
-    record_corners(r0, r1, r2, code, 0u, a0, a1, a2);
-    record_corners(r0, r1, r2, code, 1u, b0, b1, b2);
-    float ta, ua, va, tb, ub, vb;
-    const bool oka = tri_test(a0, sub(a1, a0), sub(a2, a0), o, d, tnear, ta, ua, va);
-    const bool okb = tri_test(b0, sub(b1, b0), sub(b2, b0), o, d, tnear, tb, ub, vb) && gidx1 != RT_EMPTY;
-    take_candidate(ta, gidx0, 2u * slot, ua, va, oka, best);
-    take_candidate(tb, gidx1, 2u * slot + 1u, ub, vb, okb, best);
+    // one triangle after the other: letting the compiler interleave the two tests costs ~20 registers, and the
+    // traversal kernel gains more from the extra resident wave than from the overlap
+    {
+        V3 v0, v1, v2;
+        record_corners(r0, r1, r2, code, 0u, v0, v1, v2);
+        float t, u, v;
+        const bool ok = tri_test(v0, sub(v1, v0), sub(v2, v0), o, d, tnear, t, u, v);
+        take_candidate(t, gidx0, 2u * slot, u, v, ok, best);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    {
+        V3 v0, v1, v2;
+        record_corners(r0, r1, r2, code, 1u, v0, v1, v2);
+        float t, u, v;
+        const bool ok = tri_test(v0, sub(v1, v0), sub(v2, v0), o, d, tnear, t, u, v) && gidx1 != RT_EMPTY;
+        take_candidate(t, gidx1, 2u * slot + 1u, u, v, ok, best);
+    }
 }
 
 // Geometric normal (not normalised) of the accepted candidate, the word holding its geometry id and the global index
 // of the first primitive of that geometry.  A sphere's roots are evaluated again: the same operations on the same
 // operands give the same bits as during the test, and the front root is the one taken when both equal t.
 RT_DEV V3 candidate_normal(const SceneView &sv, uint32_t slot2, V3 o, V3 d, float t, uint32_t &code, uint32_t &geom_first) {
-    const F4 *p = sv.prims + (size_t)(slot2 >> 1) * RT_PRIM_F4;
+    const F4 *p = record_at(sv, slot2 >> 1);
     F4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
     code = __builtin_bit_cast(uint32_t, r3.z);
     geom_first = __builtin_bit_cast(uint32_t, r3.w);
@@ -602,8 +623,17 @@ RT_DEV V3 candidate_normal(const SceneView &sv, uint32_t slot2, V3 o, V3 d, floa
     return cross(sub(v1, v0), sub(v2, v0));
 }
 
-// Reciprocal that never produces inf, so that 0 * inv is 0 and not NaN in the slab test.
-RT_DEV float safe_rcp(float d) { return 1.0f / (fabsf(d) > 1e-20f ? d : copysignf(1e-20f, d)); }
+// Reciprocal that never produces inf, so that 0 * inv is 0 and not NaN in the slab test.  It only feeds the
+// conservative box test (whose padding absorbs an error of a few ulp), never a hit, so the device uses the hardware
+// approximation (1 ulp) instead of an IEEE division.
+RT_DEV float safe_rcp(float d) {
+    const float x = fabsf(d) > 1e-20f ? d : copysignf(1e-20f, d);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
 
 // Traversal state of one ray: reciprocal direction, the node or leaf to visit next (RT_EMPTY = finished) and the best
 // candidate so far.  The stack is separate (`Stack` offers push(uint32_t) / pop() / empty()); the tree's worst-case
@@ -634,7 +664,7 @@ RT_DEV void trav_begin(const SceneView &sv, V3 o, V3 d, float tfar, Trav &tr) {
 // padded at build time), so it uses fused multiply-adds; it never decides a hit.
 template <class Stack>
 RT_DEV void trav_node_step(const SceneView &sv, float tnear, Trav &tr, Stack &st) {
-    const U4 *n = reinterpret_cast<const U4 *>(sv.nodes) + (size_t)tr.cur * RT_NODE_F4;
+    const U4 *n = node_at(sv, tr.cur);
     const U4 w0 = n[0], w1 = n[1], w2 = n[2], w3 = n[3];
     const uint32_t ch[4] = {w3.x, w3.y, w3.z, w3.w};
     // plane distance = (origin + q * step - o) / d = q * (step / d) + (origin / d - o / d)
@@ -644,20 +674,24 @@ RT_DEV void trav_node_step(const SceneView &sv, float tnear, Trav &tr, Stack &st
     const float bx = __builtin_fmaf(__builtin_bit_cast(float, w0.x), tr.ix, tr.nox);
     const float by = __builtin_fmaf(__builtin_bit_cast(float, w0.y), tr.iy, tr.noy);
     const float bz = __builtin_fmaf(__builtin_bit_cast(float, w0.z), tr.iz, tr.noz);
-    const uint32_t qlx = w1.z, qly = w1.w, qlz = w2.x, qhx = w2.y, qhy = w2.z, qhz = w2.w;
+    // the plane a ray meets first on an axis is the low one when it travels in the positive direction
+    const bool nx = tr.ix < 0.0f, ny = tr.iy < 0.0f, nz = tr.iz < 0.0f;
+    const uint32_t qnx = nx ? w2.y : w1.z, qfx = nx ? w1.z : w2.y;
+    const uint32_t qny = ny ? w2.z : w1.w, qfy = ny ? w1.w : w2.z;
+    const uint32_t qnz = nz ? w2.w : w2.x, qfz = nz ? w2.x : w2.w;
     const float tfar = tr.best.t;
     float tn[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int sh = 8 * k;
-        const float t0x = __builtin_fmaf((float)((qlx >> sh) & 255u), sx, bx);
-        const float t1x = __builtin_fmaf((float)((qhx >> sh) & 255u), sx, bx);
-        const float t0y = __builtin_fmaf((float)((qly >> sh) & 255u), sy, by);
-        const float t1y = __builtin_fmaf((float)((qhy >> sh) & 255u), sy, by);
-        const float t0z = __builtin_fmaf((float)((qlz >> sh) & 255u), sz, bz);
-        const float t1z = __builtin_fmaf((float)((qhz >> sh) & 255u), sz, bz);
-        const float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tnear));
-        const float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tfar));
+        const float t0x = __builtin_fmaf((float)((qnx >> sh) & 255u), sx, bx);
+        const float t1x = __builtin_fmaf((float)((qfx >> sh) & 255u), sx, bx);
+        const float t0y = __builtin_fmaf((float)((qny >> sh) & 255u), sy, by);
+        const float t1y = __builtin_fmaf((float)((qfy >> sh) & 255u), sy, by);
+        const float t0z = __builtin_fmaf((float)((qnz >> sh) & 255u), sz, bz);
+        const float t1z = __builtin_fmaf((float)((qfz >> sh) & 255u), sz, bz);
+        const float tmin = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, tnear));
+        const float tmax = fminf(fminf(t1x, t1y), fminf(t1z, tfar));
         const bool hit = (ch[k] != RT_EMPTY) && (tmin <= tmax * 1.0000004f);
         tn[k] = hit ? tmin : INFINITY;
     }

@@ -305,6 +305,8 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
     if (progress) cb = [progress, user](double a) { return progress(a, user) != 0; };
     if (!rts::build_scene(scene->prims, bvh, prims, scene->lo, scene->hi, cb))
         return fail(RTMI_ERR_CANCELLED, "commit cancelled by the progress callback");
+    if (bvh.n_nodes >= rtd::RT_MAX_ITEMS || prims.size() / rtd::RT_PRIM_F4 >= rtd::RT_MAX_ITEMS)
+        return fail(RTMI_ERR_LIMIT, "scene too large: more than 2^26 BVH nodes or primitive records");
     if (bvh.stack_need > rtk::MAX_STACK)
         return fail(RTMI_ERR_LIMIT, "BVH needs a deeper traversal stack than the kernels provide");
     free_scene_device(scene);
@@ -544,8 +546,9 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     const size_t padded_pix = n_blocks * rtk::PIXEL_BLOCK;
     const size_t seg_blocks = (n_blocks + rtk::SEGMENTS - 1) / rtk::SEGMENTS;
     const size_t queue_pix = seg_blocks * rtk::SEGMENTS * rtk::PIXEL_BLOCK; // per sample, all segments
-    if ((size_t)spp_pass * queue_pix >= (1ull << 31))
-        spp_pass = (uint32_t)std::max<size_t>(1, ((1ull << 31) - 1) / queue_pix);
+    // a plane of path or queue data is addressed with a 32-bit byte offset
+    if ((size_t)spp_pass * queue_pix >= (1ull << 30))
+        spp_pass = (uint32_t)std::max<size_t>(1, ((1ull << 30) - 1) / queue_pix);
     const size_t max_paths = (size_t)spp_pass * queue_pix;
     const uint32_t n_passes = (n_samples + spp_pass - 1) / spp_pass;
     // counters of one pass (reused by the next): SEGMENTS per bounce, each on its own 256-byte line
@@ -606,6 +609,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.leaf_bias = 0;
     if (const char *v = getenv("RTMI_REFILL_BELOW")) a.refill_below = atoi(v);
     if (const char *v = getenv("RTMI_LEAF_BIAS")) a.leaf_bias = atoi(v);
+    a.refill_below = std::max(1, std::min(64, a.refill_below)); // below 1 a drained wave would never flush
     a.spill = scene->d_spill;
     const uint32_t full_grid = scene->grid_blocks;
 
@@ -634,6 +638,10 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             break;
         }
         (void)hipEventRecord(ev_pass[2 * pass], stream);
+        if (rtk::launch_raygen(a, stream)) {
+            rc = fail(RTMI_ERR_DEVICE, "raygen kernel launch failed");
+            break;
+        }
         uint64_t live = (uint64_t)k * npix; // rays entering the bounce about to be launched
         uint32_t longest = a.seg_cap;       // entries of the longest segment at that bounce
         paths += live;
