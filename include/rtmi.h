@@ -114,9 +114,9 @@ typedef struct rtmi_render_stats {
     uint32_t passes; /* wavefront passes run */
     uint32_t max_bounces; /* deepest bounce that still had live paths */
     float gpu_ms;    /* device time of the call, from HIP events on the render stream */
-    float bounce_ms; /* of which: between the first and the last bounce-kernel launch of every pass */
-    uint32_t bounce_launches; /* bounce-kernel launches issued */
-    uint32_t reserved;
+    float bounce_ms; /* of which: from the camera-ray kernel to the last bounce's kernels of every pass */
+    uint32_t bounce_launches; /* closest-hit (traversal) kernel launches issued, one per bounce and pass */
+    float extend_ms; /* device time inside those closest-hit kernel launches, from HIP events around each launch */
 } rtmi_render_stats;
 
 typedef struct rtmi_scene_info {

@@ -169,14 +169,12 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(RenderArgs a) {
 //
 // Hit record of queue entry i of segment x, at plane offset x * seg_cap + i: distance (+inf = miss), geometric normal
 // (not normalised), geometry word.  Rays come from the bounce's payload planes, in queue order.
-//
-// PRIMARY: bounce 0, whose queue has padding entries (zero direction) that are skipped.  COUNT: tally node visits and
-// primitive tests.
-template <bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t depth_arg) {
+// The queue of bounce 0 has padding entries (zero direction) that are skipped.
+__global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t depth) {
     __shared__ uint32_t lds[LDS_STACK * BLOCK];
     LaneStack st = make_stack(lds, a.spill);
-    const uint32_t depth = PRIMARY ? 0u : depth_arg;
+    const bool primary = depth == 0u;
+    const bool count = a.visit_counters != nullptr; // tally node visits and primitive tests
     const size_t H = (size_t)SEGMENTS * a.seg_cap;
     float *__restrict__ hits = a.hits;
     const float *__restrict__ Q = a.payload[depth & 1u]; // this bounce's rays, in queue order
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t de
                     const uint32_t pos = seg * a.seg_cap + i;
                     org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
                     dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
-                    if (!PRIMARY || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
+                    if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
                         slot_out = pos;
                         st.sp = 0;
                         trav_begin(a.scene, org, dir, INFINITY, tr);
@@ -267,17 +265,17 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t de
         const int n_leaf = (int)__popcll(__ballot(at_leaf));
         if (n_leaf == 0 || (n_node > 0 && n_node >= n_leaf + a.leaf_bias)) {
             if (at_node) {
-                if (COUNT) ++nodes;
+                if (count) ++nodes;
                 trav_node_step(a.scene, RT_TNEAR, tr, st);
             }
         } else {
             if (at_leaf) {
-                if (COUNT) ++tests;
+                if (count) ++tests;
                 trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
             }
         }
     }
-    if (COUNT) {
+    if (count) {
         // wave-level sums, then one 64-bit atomic pair per wave
         for (int off = 32; off > 0; off >>= 1) {
             nodes += __shfl_down(nodes, off);
@@ -528,18 +526,7 @@ int launch_intersect(const SceneView &scene, const RayAoS *d_rays, HitAoS *d_hit
 
 int launch_extend(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    const bool count = args.visit_counters != nullptr;
-    if (depth == 0u) {
-        if (count)
-            hipLaunchKernelGGL((extend_kernel<true, true>), dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
-        else
-            hipLaunchKernelGGL((extend_kernel<true, false>), dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
-    } else {
-        if (count)
-            hipLaunchKernelGGL((extend_kernel<false, true>), dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
-        else
-            hipLaunchKernelGGL((extend_kernel<false, false>), dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
-    }
+    hipLaunchKernelGGL(extend_kernel, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
     return check_launch();
 }
 
@@ -561,8 +548,7 @@ int launch_raygen(const RenderArgs &args, void *stream) {
 
 int extend_blocks_per_cu() {
     int n = 0;
-    // the widest of the variants sizes the resident grid (and with it the stack spill buffer)
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, extend_kernel<false, false>, BLOCK, 0) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, extend_kernel, BLOCK, 0) != hipSuccess || n < 1) n = 1;
     return n;
 }
 

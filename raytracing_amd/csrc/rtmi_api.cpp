@@ -616,6 +616,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     hipEvent_t ev_begin, ev_end;
     HIP_TRY(hipEventCreate(&ev_begin));
     HIP_TRY(hipEventCreate(&ev_end));
+    std::vector<hipEvent_t> ev_extend; // pairs
     std::vector<hipEvent_t> ev_pass(2 * (size_t)n_passes);
     for (auto &e : ev_pass) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventRecord(ev_begin, stream));
@@ -655,7 +656,16 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full_grid, want_blocks));
             const uint64_t per_wave = entries / ((uint64_t)grid * waves_per_block * rtk::SEGMENTS) / 8;
             a.claim = 64u * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, per_wave / 64));
-            if (rtk::launch_extend(a, depth, grid, stream) || rtk::launch_shade(a, depth, longest, stream)) {
+            // events around the traversal launch only: its time is what the roofline of the dominant kernel needs
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) {
+                ev_extend.push_back(ev0);
+                ev_extend.push_back(ev1);
+                (void)hipEventRecord(ev0, stream);
+            }
+            int lrc = rtk::launch_extend(a, depth, grid, stream);
+            if (ev1) (void)hipEventRecord(ev1, stream);
+            if (lrc || rtk::launch_shade(a, depth, longest, stream)) {
                 rc = fail(RTMI_ERR_DEVICE, "bounce kernel launch failed");
                 break;
             }
@@ -695,9 +705,14 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             if (hipEventElapsedTime(&ms, ev_pass[2 * pass], ev_pass[2 * pass + 1]) == hipSuccess)
                 stats->bounce_ms += ms;
         }
+        for (size_t k = 0; k + 1 < ev_extend.size(); k += 2) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev_extend[k], ev_extend[k + 1]) == hipSuccess) stats->extend_ms += ms;
+        }
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->gpu_ms = ms;
     }
+    for (auto &ev : ev_extend) (void)hipEventDestroy(ev);
     (void)hipEventDestroy(ev_begin);
     (void)hipEventDestroy(ev_end);
     for (auto &ev : ev_pass) (void)hipEventDestroy(ev);
