@@ -141,6 +141,8 @@ const char *rtmi_version(void);
 
 /* embree4_rs Device::try_new (crates/rt-cli/src/main.rs:74-90).  hip_ordinal < 0 selects the current device. */
 int rtmi_device_create(int hip_ordinal, rtmi_device **out);
+/* Releases the handle.  Scenes and films created on the device keep it alive until they are destroyed too (the
+ * reference's Arc-like lifetime: CommittedScene borrows the Device), so the order of destruction is free. */
 void rtmi_device_destroy(rtmi_device *dev);
 
 /* The stream the library launches on (a hipStream_t), for callers that time or order work against it. */

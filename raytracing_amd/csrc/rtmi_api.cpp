@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -44,7 +45,21 @@ struct rtmi_device {
     bool count_visits = false;
     uint32_t *d_visits = nullptr; // two 64-bit counters
     int n_cu = 256;
+    std::atomic<int> refs{1}; // the handle itself + one per scene and film created on it
 };
+
+// A device outlives the scenes and films created on it, whatever order the caller destroys them in: the last
+// reference releases the stream and the counters.
+static void device_release(rtmi_device *dev) {
+    if (dev->refs.fetch_sub(1) != 1) return;
+    (void)hipSetDevice(dev->ordinal);
+    if (dev->stream) {
+        (void)hipStreamSynchronize(dev->stream);
+        (void)hipStreamDestroy(dev->stream);
+    }
+    if (dev->d_visits) (void)hipFree(dev->d_visits);
+    delete dev;
+}
 
 struct rtmi_scene {
     rtmi_device *dev = nullptr;
@@ -139,13 +154,7 @@ int rtmi_device_create(int hip_ordinal, rtmi_device **out) {
 
 void rtmi_device_destroy(rtmi_device *dev) {
     if (!dev) return;
-    (void)hipSetDevice(dev->ordinal);
-    if (dev->stream) {
-        (void)hipStreamSynchronize(dev->stream);
-        (void)hipStreamDestroy(dev->stream);
-    }
-    if (dev->d_visits) (void)hipFree(dev->d_visits);
-    delete dev;
+    device_release(dev);
 }
 
 int rtmi_device_count_visits(rtmi_device *dev, int enable) {
@@ -173,6 +182,7 @@ int rtmi_scene_create(rtmi_device *dev, rtmi_scene **out) {
     if (!dev || !out) return fail(RTMI_ERR_ARG, "rtmi_scene_create: NULL argument");
     rtmi_scene *s = new rtmi_scene();
     s->dev = dev;
+    dev->refs.fetch_add(1);
     rtd::Material sky{}; // embree.rs:41-46
     sky.kind = rtd::MAT_DIFFUSE;
     s->materials.push_back(sky);
@@ -185,7 +195,9 @@ void rtmi_scene_destroy(rtmi_scene *scene) {
     (void)hipSetDevice(scene->dev->ordinal);
     (void)hipStreamSynchronize(scene->dev->stream);
     free_scene_device(scene);
+    rtmi_device *dev = scene->dev;
     delete scene;
+    device_release(dev);
 }
 
 int rtmi_scene_insert_material(rtmi_scene *scene, const rtmi_material *mat, uint32_t *out_id) {
@@ -451,6 +463,7 @@ int rtmi_film_create(rtmi_device *dev, const uint32_t *xy, size_t n_pixels, floa
         delete f;
         return fail(RTMI_ERR_DEVICE, std::string("film allocation: ") + hipGetErrorString(e));
     }
+    dev->refs.fetch_add(1);
     *out = f;
     return RTMI_OK;
 }
@@ -467,7 +480,9 @@ void rtmi_film_destroy(rtmi_film *film) {
     if (film->d_queue[1]) (void)hipFree(film->d_queue[1]);
     if (film->d_counts) (void)hipFree(film->d_counts);
     if (film->d_resolve) (void)hipFree(film->d_resolve);
+    rtmi_device *dev = film->dev;
     delete film;
+    device_release(dev);
 }
 
 int rtmi_film_clear(rtmi_film *film) {

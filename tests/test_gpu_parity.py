@@ -307,6 +307,31 @@ def test_full_size_properties(oracle, scene_classes, device):
     assert same_bits(whole[:, sub], want).all()
 
 
+def test_triangle_pairing_keeps_every_triangle_exact(oracle, device):
+    """The GPU's records pair triangles that share an edge; rotated, reversed, duplicate, non-manifold and degenerate
+    triangles must still give the brute-force oracle's hits bit for bit, and a render must give its accumulators."""
+    from raytracing_amd import api, types
+    from tests.helpers import insert_pairing_torture, torture_rays
+    so, sg = oracle.OracleScene(), api.HipScene(device)
+    for s in (so, sg):
+        m = s.insert_material(types.MaterialDescriptor("m", types.DiffuseBxDF((0.7, 0.6, 0.5))))
+        insert_pairing_torture(s, m)
+    so.commit()
+    world = sg.commit().into_world()
+    rays = torture_rays(oracle.RAY_DTYPE)
+    got = world.intersect(rays)
+    want = so.intersect(rays, oracle.ISECT_BRUTE)
+    assert got.tobytes() == want.tobytes()
+    W, H = 64, 36
+    cam = types.Camera.from_dimensions(W, H)
+    xy = full_frame_xy(W, H)
+    acc_o, rays_o = so.render(cam, oracle.make_params(spp=4), xy)
+    film = api.Film(device, xy)
+    st = api.render(world, film, cam, 4)
+    assert st["rays"] == rays_o
+    assert same_bits(film.download(), acc_o).all()
+
+
 def test_deep_traversal_stack_spills(oracle, device):
     """60,000 large overlapping triangles: rays through the soup need more stack entries than the kernels keep in LDS
     (24 per lane), so the deeper entries go through the global spill buffer.  Hits must still equal brute force."""
@@ -378,3 +403,20 @@ def test_cli_writes_the_reference_outputs(device, tmp_path):
     assert jpg.shape == (36, 64, 3) and abs(int(jpg[0, 0, 2]) - 255) <= 3
     z = np.load(tmp_path / "hdr" / "Z.npy")
     assert z.shape == (36, 64) and z.max() > 0.5 and z[0, 0] == 0.0
+
+
+def test_handles_may_be_destroyed_in_any_order(device):
+    """A scene and a film outlive the device handle they were created on."""
+    from raytracing_amd import api, types
+    dev2 = api.Device(0)
+    sg = api.HipScene(dev2)
+    m = sg.insert_material(types.MaterialDescriptor("m", types.DiffuseBxDF((0.5, 0.5, 0.5))))
+    sg.insert_sphere(m, (0.0, 0.0, 3.0), 1.0)
+    world = sg.commit().into_world()
+    xy = full_frame_xy(16, 9)
+    film = api.Film(dev2, xy)
+    dev2.close()
+    st = api.render(world, film, types.Camera.from_dimensions(16, 9), 2)
+    assert st["paths"] == 2 * 16 * 9
+    film.close()
+    sg.close()

@@ -232,6 +232,24 @@ def test_bvh_finds_every_primitive(oracle, hostsim):
     assert sh.stack_high() <= sh.info["stack_need"]
 
 
+def test_triangle_pairing_keeps_every_triangle_exact(oracle, hostsim):
+    """Records hold two triangles that share an edge.  Whatever the pairing does with rotated, reversed, duplicate,
+    non-manifold and degenerate triangles, every hit (distance, barycentrics, geometry and primitive id, normal) must
+    equal the brute-force oracle's, bit for bit."""
+    from tests.helpers import insert_pairing_torture, torture_rays
+    so, sh = oracle.OracleScene(), hostsim.HostSimScene()
+    for s in (so, sh):
+        insert_pairing_torture(s)
+        s.commit()
+    assert sh.info["n_prims"] == so.prim_count()
+    rays = torture_rays(oracle.RAY_DTYPE)
+    got = sh.intersect(rays)
+    want = so.intersect(rays, oracle.ISECT_BRUTE)
+    assert (want["geom_id"] != 0xFFFFFFFF).mean() > 0.5
+    assert set(np.unique(want["geom_id"]).tolist()) >= {0, 3, 4}
+    assert got.tobytes() == want.tobytes()
+
+
 def test_host_types():
     from raytracing_amd import types
     r = types.RenderRange.parse("1..7x4..45")
