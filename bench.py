@@ -141,12 +141,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gatherer = D.FrameGatherer(xy, W, H, dev_t)
+    frame_buf = torch.zeros((api.ACCUM_PLANES, W * H), dtype=torch.float32, device=dev_t) if rank == 0 else None
+
     def step():
         accum.zero_()
         torch.cuda.synchronize()
         st = api.render(world_scene, film, camera, args.spp, None, args.max_ray_depth, 0, args.seed,
                         args.samples_per_pass)
-        frame = D.gather_frame(accum, xy, W, H)
+        frame = gatherer.gather(accum, frame_buf)
         return st, frame
 
     for _ in range(args.warmup):

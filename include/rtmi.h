@@ -174,7 +174,7 @@ int rtmi_scene_load_obj(rtmi_scene *scene, const char *path, const rtmi_transfor
                         uint32_t default_material, uint32_t *out_first_geom, uint32_t *out_n_geoms);
 
 /* EmbreeScene::commit / commit_with_progress (embree.rs:63-78): builds the SAH BVH on the host, flattens it to
- * the 4-wide GPU node / 48-byte primitive layout and uploads it.  progress (may be NULL) is called with values
+ * 4-wide 64-byte GPU nodes over 64-byte primitive records and uploads them.  progress (may be NULL) is called with values
  * in [0,1]; returning 0 cancels (RTMI_ERR_CANCELLED). */
 typedef int (*rtmi_progress_fn)(double amount, void *user);
 int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user);

@@ -1,5 +1,5 @@
 // bvh.h -- host-side acceleration structure build for the GPU kernels: binned-SAH binary BVH over padded primitive
-// boxes, collapsed to 4-wide nodes and flattened breadth-first into the 128-byte node layout of rt_device.h.
+// boxes, collapsed to 4-wide nodes and flattened breadth-first into the 64-byte quantised node layout of rt_device.h.
 // Stands in for what rtcCommitScene does inside Embree for the reference (crates/rt/src/aggregate/embree.rs:63-69).
 #pragma once
 

@@ -593,7 +593,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     }
     uint32_t *d_counts = film->d_counts;
     uint32_t *d_work = film->d_counts + film->cap_counters;
-    std::vector<uint32_t> h_counts(per_bounce);
+    std::vector<uint32_t> h_counts(per_bounce), h_all;
 
     rtk::RenderArgs a{};
     a.scene = scene->view;
@@ -658,12 +658,17 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             rc = fail(RTMI_ERR_DEVICE, "raygen kernel launch failed");
             break;
         }
-        uint64_t live = (uint64_t)k * npix; // rays entering the bounce about to be launched
-        uint32_t longest = a.seg_cap;       // entries of the longest segment at that bounce
+        // `live` / `longest`: rays entering the bounce about to be launched and the entries of its longest segment.
+        // They are exact while every bounce's survivor counters are read back; in the thin tail (fewer than
+        // tail_rays live rays) the counters are read only every fourth bounce and the last values serve as upper
+        // bounds in between (survivors never outnumber the rays that entered), which saves a host round trip per
+        // bounce where a bounce is shorter than the round trip.  Exact counts come from the counters after the pass.
+        uint64_t live = (uint64_t)k * npix;
+        uint32_t longest = a.seg_cap;
+        const uint64_t tail_rays = 1u << 18;
+        uint32_t unread = 0, launched = 0;
         paths += live;
         for (uint32_t depth = 0; depth < params->max_depth && live > 0; ++depth) {
-            rays += live;
-            if (depth > deepest) deepest = depth;
             // grid sized to the work: one wave per 64 queue entries, capped at the resident grid; a wave claims
             // several batches per atomic when the queue is long
             const uint64_t entries = depth == 0 ? (uint64_t)a.n_paths : live;
@@ -685,7 +690,10 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
                 break;
             }
             ++launches;
+            ++launched;
             if (depth + 1 == params->max_depth) break;
+            if (live < tail_rays && ++unread < 4) continue;
+            unread = 0;
             // the survivors' count sizes (or ends) the next launch
             e = hipMemcpyAsync(h_counts.data(), d_counts + (size_t)(depth + 1) * per_bounce,
                                per_bounce * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
@@ -700,6 +708,22 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
                 live += h_counts[(size_t)x * rtk::COUNTER_STRIDE];
                 longest = std::max(longest, h_counts[(size_t)x * rtk::COUNTER_STRIDE]);
             }
+        }
+        if (rc != RTMI_OK) break;
+        // exact ray count and deepest bounce of the pass from the counters of every bounce launched
+        h_all.resize((size_t)(launched + 1) * per_bounce);
+        e = hipMemcpyAsync(h_all.data(), d_counts, h_all.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) {
+            rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+            break;
+        }
+        rays += (uint64_t)k * npix;
+        for (uint32_t d = 1; d < launched; ++d) {
+            uint64_t n_d = 0;
+            for (int x = 0; x < rtk::SEGMENTS; ++x) n_d += h_all[(size_t)d * per_bounce + (size_t)x * rtk::COUNTER_STRIDE];
+            rays += n_d;
+            if (n_d > 0 && d > deepest) deepest = d;
         }
         (void)hipEventRecord(ev_pass[2 * pass + 1], stream);
         if (rc == RTMI_OK && rtk::launch_accumulate(a, film->d_accum, 1.0f, stream))

@@ -27,40 +27,54 @@ def tile_pixels(tiler, tile_indices):
     return np.concatenate(parts, 0) if parts else np.zeros((0, 2), np.uint32)
 
 
-def gather_frame(accum_local: torch.Tensor, xy_local: np.ndarray, width: int, height: int, offset=(0, 0), group=None):
-    """Gathers every rank's [ACCUM_PLANES, n_local] accumulators to rank 0 and scatters them into one
-    [ACCUM_PLANES, height * width] frame (row-major pixels).  Returns the frame on rank 0, None elsewhere.
-    Without an initialised process group this is the single-rank case."""
-    device = accum_local.device
-    lin_local = torch.from_numpy((xy_local[:, 1].astype(np.int64) - offset[1]) * width +
-                                 (xy_local[:, 0].astype(np.int64) - offset[0])).to(device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        frame = torch.zeros((ACCUM_PLANES, width * height), dtype=torch.float32, device=device)
-        frame.index_copy_(1, lin_local, accum_local)
+class FrameGatherer:
+    """The gather of one rank's accumulators into rank 0's frame, with everything that does not change from frame to
+    frame done once: the pixel -> frame index of every rank (gathered at construction), the peers' pixel counts and
+    the padded exchange buffers.  Per frame it costs one gather of [ACCUM_PLANES, n_max] floats and, on rank 0, one
+    index_copy per rank.  Without an initialised process group this is the single-rank case."""
+
+    def __init__(self, xy_local: np.ndarray, width: int, height: int, device, offset=(0, 0), group=None):
+        self.width, self.height, self.group = width, height, group
+        self.device = torch.device(device)
+        lin = (xy_local[:, 1].astype(np.int64) - offset[1]) * width + (xy_local[:, 0].astype(np.int64) - offset[0])
+        self.lin_local = torch.from_numpy(lin).to(self.device)
+        self.n_local = int(xy_local.shape[0])
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        if not self.distributed:
+            return
+        n_local = torch.tensor([self.n_local], dtype=torch.int64, device=self.device)
+        counts = [torch.zeros_like(n_local) for _ in range(self.world)]
+        dist.all_gather(counts, n_local, group=group)
+        self.counts = [int(c.item()) for c in counts]
+        self.n_max = max(self.counts)
+        pad_lin = torch.zeros((self.n_max,), dtype=torch.int64, device=self.device)
+        pad_lin[:self.n_local] = self.lin_local
+        lin_list = [torch.empty_like(pad_lin) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(pad_lin, lin_list, dst=0, group=group)
+        self.lin = [lin_list[r][:self.counts[r]] for r in range(self.world)] if self.rank == 0 else None
+        self.pad_acc = torch.zeros((ACCUM_PLANES, self.n_max), dtype=torch.float32, device=self.device)
+        self.acc_list = ([torch.empty_like(self.pad_acc) for _ in range(self.world)] if self.rank == 0 else None)
+
+    def gather(self, accum_local: torch.Tensor, frame: torch.Tensor = None):
+        """Returns the [ACCUM_PLANES, height * width] frame (row-major pixels) on rank 0, None elsewhere.  `frame`, if
+        given, is overwritten where pixels were rendered and returned."""
+        if self.rank == 0 and frame is None:
+            frame = torch.zeros((ACCUM_PLANES, self.width * self.height), dtype=torch.float32, device=self.device)
+        if not self.distributed:
+            frame.index_copy_(1, self.lin_local, accum_local)
+            return frame
+        self.pad_acc[:, :self.n_local] = accum_local
+        dist.gather(self.pad_acc, self.acc_list, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        for r in range(self.world):
+            frame.index_copy_(1, self.lin[r], self.acc_list[r][:, :self.counts[r]])
         return frame
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    n_local = torch.tensor([accum_local.shape[1]], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    n_max = max(counts)
-    # payload: accumulator planes plus the pixel index (as f32 bit patterns of two 16-bit halves would lose nothing,
-    # but a separate int64 gather is simpler and tiny)
-    pad_acc = torch.zeros((ACCUM_PLANES, n_max), dtype=torch.float32, device=device)
-    pad_acc[:, :accum_local.shape[1]] = accum_local
-    pad_lin = torch.zeros((n_max,), dtype=torch.int64, device=device)
-    pad_lin[:lin_local.shape[0]] = lin_local
-    if rank == 0:
-        acc_list = [torch.empty_like(pad_acc) for _ in range(world)]
-        lin_list = [torch.empty_like(pad_lin) for _ in range(world)]
-    else:
-        acc_list = lin_list = None
-    dist.gather(pad_acc, acc_list, dst=0, group=group)
-    dist.gather(pad_lin, lin_list, dst=0, group=group)
-    if rank != 0:
-        return None
-    frame = torch.zeros((ACCUM_PLANES, width * height), dtype=torch.float32, device=device)
-    for r in range(world):
-        frame.index_copy_(1, lin_list[r][:counts[r]], acc_list[r][:, :counts[r]])
-    return frame
+
+
+def gather_frame(accum_local: torch.Tensor, xy_local: np.ndarray, width: int, height: int, offset=(0, 0), group=None):
+    """One-off form of FrameGatherer: gathers every rank's [ACCUM_PLANES, n_local] accumulators to rank 0 and scatters
+    them into one frame.  Returns the frame on rank 0, None elsewhere."""
+    return FrameGatherer(xy_local, width, height, accum_local.device, offset, group).gather(accum_local)

@@ -335,3 +335,121 @@ void hs_depth_stats(void *p, const CameraView *cam, const Params *prm, const uin
 const void *hs_view(void *p) { return &((Scene *)p)->view; }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------- wave scheduling model
+//
+// Replays the traversal kernel's lane scheduling for waves of 64 rays on the host, with an issue-cost model, to compare
+// scheduling policies before writing them for the GPU.  policy 0: every step the wave runs the phase (node / record)
+// most busy lanes wait for.  policy 1: a lane that reaches a record parks it in a queue of `depth` entries and goes on
+// with the next stack entry; records are tested when `leaf_lanes` lanes have parked records, a lane is blocked, or no
+// lane has a node to visit.  Finished lanes are refilled when fewer than refill_below lanes are busy.
+// out: issue cost, useful cost, node steps, record steps, node phases, record phases, refills
+extern "C" void hs_wave_sim(void *p, const Ray *rays, size_t n, int policy, int refill_below, int depth, int leaf_lanes,
+                            const double cost[4], double out[8]) {
+    Scene *s = (Scene *)p;
+    const double c_node = cost[0], c_leaf = cost[1], c_refill = cost[2], c_iter = cost[3];
+    struct Lane {
+        bool has = false;
+        V3 o, d;
+        Trav tr;
+        VecStack st;
+        uint32_t pend[8];
+        int np = 0;
+    };
+    for (int k = 0; k < 8; ++k) out[k] = 0.0;
+    size_t next = 0;
+    while (next < n) {
+        // one persistent wave takes up to 4096 rays (a claimed range), then the next wave starts
+        const size_t wave_end = std::min(n, next + 4096);
+        std::vector<Lane> L(64);
+        for (;;) {
+            int n_busy = 0;
+            for (auto &l : L)
+                if (l.has && (l.tr.cur != RT_EMPTY || l.np > 0)) ++n_busy;
+            if (n_busy < refill_below || n_busy == 0) {
+                bool any = false;
+                for (auto &l : L) {
+                    if (l.has && l.tr.cur == RT_EMPTY && l.np == 0) l.has = false, any = true;
+                    if (!l.has && next < wave_end) {
+                        const Ray &r = rays[next++];
+                        l.o = mk(r.org[0], r.org[1], r.org[2]);
+                        l.d = mk(r.dir[0], r.dir[1], r.dir[2]);
+                        l.st = VecStack();
+                        trav_begin(s->view, l.o, l.d, INFINITY, l.tr);
+                        l.np = 0;
+                        l.has = true;
+                        any = true;
+                    }
+                }
+                if (any) out[0] += 64.0 * c_refill, out[6] += 1.0;
+                n_busy = 0;
+                for (auto &l : L)
+                    if (l.has && (l.tr.cur != RT_EMPTY || l.np > 0)) ++n_busy;
+                if (n_busy == 0) {
+                    if (next >= wave_end) break;
+                    continue;
+                }
+            }
+            out[0] += 64.0 * c_iter;
+            if (policy >= 1) {
+                // park records (bounded work per iteration: two moves)
+                for (auto &l : L)
+                    for (int m = 0; m < 2; ++m)
+                        if (l.has && l.tr.cur != RT_EMPTY && (l.tr.cur & RT_LEAF) && l.np < depth) {
+                            l.pend[l.np++] = l.tr.cur;
+                            l.tr.cur = l.st.empty() ? RT_EMPTY : l.st.pop();
+                        }
+            }
+            int n_node = 0, n_leaf = 0, n_blocked = 0;
+            for (auto &l : L) {
+                if (!l.has) continue;
+                const bool at_node = l.tr.cur != RT_EMPTY && !(l.tr.cur & RT_LEAF);
+                if (at_node) ++n_node;
+                if (policy == 0) {
+                    if (l.tr.cur != RT_EMPTY && (l.tr.cur & RT_LEAF)) ++n_leaf;
+                } else {
+                    if (l.np > 0) ++n_leaf;
+                    if (l.tr.cur != RT_EMPTY && (l.tr.cur & RT_LEAF)) ++n_blocked; // queue full
+                }
+            }
+            bool node_phase;
+            if (policy == 0)
+                node_phase = n_leaf == 0 || (n_node > 0 && n_node >= n_leaf);
+            else if (policy == 1)
+                node_phase = n_node > 0 && n_blocked == 0 && n_leaf < leaf_lanes;
+            else
+                node_phase = n_node > 0 && n_leaf < leaf_lanes; // blocked lanes wait
+            if (node_phase) {
+                out[0] += 64.0 * c_node;
+                out[4] += 1.0;
+                for (auto &l : L)
+                    if (l.has && l.tr.cur != RT_EMPTY && !(l.tr.cur & RT_LEAF)) {
+                        trav_node_step(s->view, RT_TNEAR, l.tr, l.st);
+                        out[1] += c_node;
+                        out[2] += 1.0;
+                    }
+            } else {
+                out[0] += 64.0 * c_leaf;
+                out[5] += 1.0;
+                for (auto &l : L) {
+                    if (!l.has) continue;
+                    if (policy == 0) {
+                        if (l.tr.cur != RT_EMPTY && (l.tr.cur & RT_LEAF)) {
+                            trav_leaf_step(s->view, l.o, l.d, RT_TNEAR, l.tr, l.st);
+                            out[1] += c_leaf;
+                            out[3] += 1.0;
+                        }
+                    } else if (l.np > 0) {
+                        // oldest parked record first (it was the nearest when parked)
+                        const uint32_t ref = l.pend[0];
+                        for (int k = 1; k < l.np; ++k) l.pend[k - 1] = l.pend[k];
+                        --l.np;
+                        test_prim(s->view, ref & 0x0FFFFFFFu, l.o, l.d, RT_TNEAR, l.tr.best);
+                        out[1] += c_leaf;
+                        out[3] += 1.0;
+                    }
+                }
+            }
+        }
+    }
+}

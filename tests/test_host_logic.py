@@ -294,10 +294,16 @@ def _rank_main(rank, world, port, W, H, spp, out_path):
     xy = D.tile_pixels(tiler, D.partition_tiles(tiler.tile_count(), world, rank))
     acc, _ = so.render(cam, O.make_params(spp=spp, threads=2), xy)  # the oracle stands in for the GPU renderer
     frame = D.gather_frame(torch.from_numpy(acc), xy, W, H)
+    # the reusable form, two frames in a row into one buffer: the second frame must replace the first
+    g = D.FrameGatherer(xy, W, H, "cpu")
+    buf = torch.zeros((22, W * H)) if rank == 0 else None
+    g.gather(torch.from_numpy(acc) * 2.0, buf)
+    again = g.gather(torch.from_numpy(acc), buf)
     if rank == 0:
+        assert again is buf and torch.equal(again, frame)
         np.save(out_path, frame.numpy())
     else:
-        assert frame is None
+        assert frame is None and again is None
     dist.barrier()
     dist.destroy_process_group()
 
