@@ -117,6 +117,7 @@ typedef struct rtmi_render_stats {
     float bounce_ms; /* of which: from the camera-ray kernel to the last bounce's kernels of every pass */
     uint32_t bounce_launches; /* closest-hit (traversal) kernel launches issued, one per bounce and pass */
     float extend_ms; /* device time inside those closest-hit kernel launches, from HIP events around each launch */
+    uint64_t tail_rays; /* of `rays`: traced by the run-to-completion kernel that finishes the last few paths of a pass */
 } rtmi_render_stats;
 
 typedef struct rtmi_scene_info {

@@ -48,7 +48,8 @@ class RenderParams(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("passes", C.c_uint32), ("max_bounces", C.c_uint32),
-                ("gpu_ms", C.c_float), ("bounce_ms", C.c_float), ("bounce_launches", C.c_uint32), ("extend_ms", C.c_float)]
+                ("gpu_ms", C.c_float), ("bounce_ms", C.c_float), ("bounce_launches", C.c_uint32), ("extend_ms", C.c_float),
+                ("tail_rays", C.c_uint64)]
 
 
 class SceneInfo(C.Structure):

@@ -384,14 +384,14 @@ class Executor:
         offsets = np.cumsum([0] + [len(t) for t in tile_list])
         film = Film(world.scene.device, xy)
         stats = {"rays": 0, "paths": 0, "passes": 0, "gpu_ms": 0.0, "bounce_ms": 0.0, "max_bounces": 0,
-                 "bounce_launches": 0, "extend_ms": 0.0}
+                 "bounce_launches": 0, "extend_ms": 0.0, "tail_rays": 0}
         try:
             cur = sample_range.start
             while cur < sample_range.stop:
                 n = min(batch_size, sample_range.stop - cur) if batch_size else sample_range.stop - cur
                 st = render(world, film, self.camera, self.spp, range(cur, cur + n), self.max_depth,
                             INTEGRATORS[self.integrator], self.seed, 0, self.allowed_error or 0.0)
-                for k in ("rays", "paths", "passes", "gpu_ms", "bounce_ms", "bounce_launches", "extend_ms"):
+                for k in ("rays", "paths", "passes", "gpu_ms", "bounce_ms", "bounce_launches", "extend_ms", "tail_rays"):
                     stats[k] += st[k]
                 stats["max_bounces"] = max(stats["max_bounces"], st["max_bounces"])
                 cur += n

@@ -402,6 +402,68 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
     }
 }
 
+// The thin tail of a pass: once few paths are left, a launch per bounce costs more than the bounce (the kernels are
+// latency-bound with a few thousand rays), so this kernel takes every path still alive at bounce `depth0` and runs it
+// to its end, one path per lane: closest hit, shading, next ray, in the same per-ray functions as the two kernels
+// above (results do not depend on which kernel traces a path).  Every bounce the wave adds its live lanes to the
+// counter of that bounce, so the counters read like those of the wavefront kernels.
+__global__ __launch_bounds__(BLOCK) void tail_kernel(RenderArgs a, uint32_t depth0) {
+    __shared__ uint32_t lds[LDS_STACK * BLOCK];
+    LaneStack st = make_stack(lds, a.spill);
+    const uint32_t seg = blockIdx.x % (uint32_t)SEGMENTS;
+    const uint32_t i = (blockIdx.x / (uint32_t)SEGMENTS) * (uint32_t)BLOCK + threadIdx.x;
+    const uint32_t n_in = segment_entries(a, depth0, seg);
+    const size_t P = a.n_paths;
+    const size_t H = (size_t)SEGMENTS * a.seg_cap;
+    float *__restrict__ S = a.state;
+    const float *__restrict__ Q = a.payload[depth0 & 1u];
+    const uint32_t pos = seg * a.seg_cap + i;
+    bool alive = i < n_in;
+    uint32_t pid = 0, x = 0, y = 0, sample = 0;
+    V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f), beta = mk(0.0f, 0.0f, 0.0f);
+    float ray_depth = 0.0f;
+    if (alive) {
+        const Entry e = queue_entry(a, depth0, seg, i, Q + (size_t)seg * a.seg_cap);
+        pid = e.pid;
+        sample = e.sample;
+        x = a.pixels[2 * e.pix];
+        y = a.pixels[2 * e.pix + 1];
+        org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+        dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
+        beta = mk(ldp(Q + 7 * H, pos), ldp(Q + 8 * H, pos), ldp(Q + 9 * H, pos));
+        ray_depth = ldp(Q + 10 * H, pos);
+    }
+    for (uint32_t depth = depth0; depth < a.max_depth; ++depth) {
+        if (alive) {
+            st.sp = 0;
+            st.shallow = false;
+            Closest best;
+            closest_hit(a.scene, org, dir, RT_TNEAR, INFINITY, st, best, (uint32_t *)nullptr, (uint32_t *)nullptr);
+            HitInfo h;
+            finish_hit(a.scene, org, dir, best, h);
+            VertexOut vo;
+            bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, x, y, sample, depth, org, dir, beta, vo);
+            if (h.hit && vo.t_add != 0.0f) ray_depth = ray_depth + vo.t_add;
+            if (cont && depth + 1u == a.max_depth) {
+                // the next vertex would be at the depth limit: it contributes beta * 0 (pathtracing.rs:24-26)
+                vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
+                cont = false;
+            }
+            if (!cont) {
+                stp(S + 0 * P, pid, vo.radiance.x);
+                stp(S + 1 * P, pid, vo.radiance.y);
+                stp(S + 2 * P, pid, vo.radiance.z);
+                stp(S + 13 * P, pid, ray_depth);
+                alive = false;
+            }
+        }
+        const unsigned long long amask = __ballot(alive);
+        if (amask == 0ull) break;
+        if (rank_in(~0ull) == 0u)
+            atomicAdd(&a.counts[(size_t)((depth + 1u) * SEGMENTS + seg) * COUNTER_STRIDE], (uint32_t)__popcll(amask));
+    }
+}
+
 // crates/rt/src/math/stat.rs:45-52
 __device__ __forceinline__ float variance_of(float count, float sum, float sqsum) {
     if (count <= 2.0f) return INFINITY;
@@ -535,6 +597,14 @@ int launch_shade(const RenderArgs &args, uint32_t depth, uint32_t max_segment_en
     hipStream_t s = (hipStream_t)stream;
     const uint32_t per_seg = (max_segment_entries + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(shade_kernel, dim3(per_seg * SEGMENTS), dim3(BLOCK), 0, s, args, depth);
+    return check_launch();
+}
+
+int launch_tail(const RenderArgs &args, uint32_t depth0, uint32_t max_segment_entries, void *stream) {
+    if (max_segment_entries == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t per_seg = (max_segment_entries + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(tail_kernel, dim3(per_seg * SEGMENTS), dim3(BLOCK), 0, s, args, depth0);
     return check_launch();
 }
 

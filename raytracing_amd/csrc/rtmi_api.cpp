@@ -637,7 +637,9 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     HIP_TRY(hipEventRecord(ev_begin, stream));
     int rc = RTMI_OK;
     uint32_t sample = params->sample_begin;
-    uint64_t rays = 0, paths = 0;
+    uint64_t rays = 0, paths = 0, tail_rays_traced = 0;
+    uint64_t tail_rays = 1u << 18;
+    if (const char *v = getenv("RTMI_TAIL_RAYS")) tail_rays = (uint64_t)atoll(v);
     uint32_t deepest = 0, launches = 0;
     const uint32_t waves_per_block = rtk::BLOCK / 64;
     for (uint32_t pass = 0; pass < n_passes && rc == RTMI_OK; ++pass) {
@@ -658,17 +660,21 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             rc = fail(RTMI_ERR_DEVICE, "raygen kernel launch failed");
             break;
         }
-        // `live` / `longest`: rays entering the bounce about to be launched and the entries of its longest segment.
-        // They are exact while every bounce's survivor counters are read back; in the thin tail (fewer than
-        // tail_rays live rays) the counters are read only every fourth bounce and the last values serve as upper
-        // bounds in between (survivors never outnumber the rays that entered), which saves a host round trip per
-        // bounce where a bounce is shorter than the round trip.  Exact counts come from the counters after the pass.
+        // `live` / `longest`: rays entering the bounce about to be launched and the entries of its longest segment,
+        // from the survivor counters read back after every bounce.  Once fewer than tail_rays are left a launch per
+        // bounce costs more than the bounce, and one tail_kernel launch runs the remaining paths to their end.
         uint64_t live = (uint64_t)k * npix;
         uint32_t longest = a.seg_cap;
-        const uint64_t tail_rays = 1u << 18;
-        uint32_t unread = 0, launched = 0;
+        uint32_t launched = 0, tail_from = 0; // bounces whose counters are valid; first bounce of the tail (0 = none)
         paths += live;
         for (uint32_t depth = 0; depth < params->max_depth && live > 0; ++depth) {
+            if (depth > 0 && live < tail_rays &&
+                (uint64_t)((longest + rtk::BLOCK - 1) / rtk::BLOCK) * rtk::SEGMENTS <= full_grid) {
+                if (rtk::launch_tail(a, depth, longest, stream)) rc = fail(RTMI_ERR_DEVICE, "tail kernel launch failed");
+                tail_from = depth;
+                launched = params->max_depth;
+                break;
+            }
             // grid sized to the work: one wave per 64 queue entries, capped at the resident grid; a wave claims
             // several batches per atomic when the queue is long
             const uint64_t entries = depth == 0 ? (uint64_t)a.n_paths : live;
@@ -692,8 +698,6 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             ++launches;
             ++launched;
             if (depth + 1 == params->max_depth) break;
-            if (live < tail_rays && ++unread < 4) continue;
-            unread = 0;
             // the survivors' count sizes (or ends) the next launch
             e = hipMemcpyAsync(h_counts.data(), d_counts + (size_t)(depth + 1) * per_bounce,
                                per_bounce * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
@@ -710,21 +714,34 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             }
         }
         if (rc != RTMI_OK) break;
-        // exact ray count and deepest bounce of the pass from the counters of every bounce launched
-        h_all.resize((size_t)(launched + 1) * per_bounce);
-        e = hipMemcpyAsync(h_all.data(), d_counts, h_all.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) {
-            rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
-            break;
-        }
+        // exact ray count and deepest bounce of the pass from the counters of every bounce that ran (read in chunks
+        // of 256 bounces up to the first empty one: live counts never grow from one bounce to the next)
         rays += (uint64_t)k * npix;
-        for (uint32_t d = 1; d < launched; ++d) {
-            uint64_t n_d = 0;
-            for (int x = 0; x < rtk::SEGMENTS; ++x) n_d += h_all[(size_t)d * per_bounce + (size_t)x * rtk::COUNTER_STRIDE];
-            rays += n_d;
-            if (n_d > 0 && d > deepest) deepest = d;
+        bool ended = false;
+        for (uint32_t d0 = 1; d0 < launched && !ended; d0 += 256) {
+            const uint32_t d1 = std::min(launched, d0 + 256);
+            h_all.resize((size_t)(d1 - d0) * per_bounce);
+            e = hipMemcpyAsync(h_all.data(), d_counts + (size_t)d0 * per_bounce, h_all.size() * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+                break;
+            }
+            for (uint32_t d = d0; d < d1; ++d) {
+                uint64_t n_d = 0;
+                for (int x = 0; x < rtk::SEGMENTS; ++x)
+                    n_d += h_all[(size_t)(d - d0) * per_bounce + (size_t)x * rtk::COUNTER_STRIDE];
+                if (n_d == 0) {
+                    ended = true;
+                    break;
+                }
+                rays += n_d;
+                if (tail_from != 0 && d >= tail_from) tail_rays_traced += n_d;
+                if (d > deepest) deepest = d;
+            }
         }
+        if (rc != RTMI_OK) break;
         (void)hipEventRecord(ev_pass[2 * pass + 1], stream);
         if (rc == RTMI_OK && rtk::launch_accumulate(a, film->d_accum, 1.0f, stream))
             rc = fail(RTMI_ERR_DEVICE, "accumulate kernel launch failed");
@@ -735,6 +752,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     if (rc == RTMI_OK && e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
     if (rc == RTMI_OK && stats) {
         stats->rays = rays;
+        stats->tail_rays = tail_rays_traced;
         stats->paths = paths;
         stats->max_bounces = deepest;
         stats->passes = n_passes;

@@ -141,11 +141,23 @@ def render_both(oracle, so, world, device, width, height, spp, max_depth=64, see
     ("dragon", (128, 72), 6, {"levels": 2}),
     ("dragon", (128, 72), 4, {"levels": 2, "diffuse": True}),
 ])
-def test_accumulators_bit_equal_to_oracle(oracle, scene_classes, device, name, size, spp, kw):
+@pytest.mark.parametrize("tail", ["kernels per bounce", "tail kernel", "tail kernel late"])
+def test_accumulators_bit_equal_to_oracle(oracle, scene_classes, device, monkeypatch, name, size, spp, kw, tail):
+    """Frames this small fall below the library's tail threshold after the first bounce, so by default every later
+    bounce runs in tail_kernel; RTMI_TAIL_RAYS=0 keeps the per-bounce extend / shade kernels to the end, and a
+    threshold of a few thousand rays switches in the middle of the path."""
+    if tail == "kernels per bounce":
+        monkeypatch.setenv("RTMI_TAIL_RAYS", "0")
+    elif tail == "tail kernel late":
+        monkeypatch.setenv("RTMI_TAIL_RAYS", "3000")
     so, world = build_pair(oracle, scene_classes[name], device, **kw)
     got, st, want, want_rays = render_both(oracle, so, world, device, size[0], size[1], spp)
     assert st["rays"] == want_rays
     assert st["paths"] == size[0] * size[1] * spp
+    if tail == "kernels per bounce":
+        assert st["tail_rays"] == 0
+    elif tail == "tail kernel":
+        assert st["tail_rays"] > 0 or st["rays"] == st["paths"]
     eq = same_bits(got, want)
     assert eq.all(), "%d of %d accumulator words differ" % ((~eq).sum(), eq.size)
 

@@ -50,7 +50,7 @@ def test_structure_layouts_match_the_header():
     assert C.sizeof(_lib.Material) == 32
     assert _lib.RAY_DTYPE.itemsize == 32 and _lib.HIT_DTYPE.itemsize == 48
     assert C.sizeof(_lib.Camera) == 52 and C.sizeof(_lib.TransformPOD) == 40
-    assert C.sizeof(_lib.RenderParams) == 40 and C.sizeof(_lib.RenderStats) == 40
+    assert C.sizeof(_lib.RenderParams) == 40 and C.sizeof(_lib.RenderStats) == 48
     assert C.sizeof(_lib.SceneInfo) == 56
 
 
