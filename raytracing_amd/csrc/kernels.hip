@@ -60,36 +60,82 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Batch closest hit (Shape::intersection_full for n rays).  Same lane scheduling as extend_kernel below: every wave
+// owns a contiguous slice of the batch, a lane whose ray has finished waits until a quarter of the wave is idle, then
+// the idle lanes write their hits and take the next rays of the slice, and every step the wave runs the phase (inner
+// node or primitive record) most of its busy lanes wait for.
 __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const RayAoS *__restrict__ rays,
                                                           HitAoS *__restrict__ hits, uint64_t n, uint32_t *spill) {
     __shared__ uint32_t lds[LDS_STACK * BLOCK];
     LaneStack st = make_stack(lds, spill);
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
-        const F4 *rp = reinterpret_cast<const F4 *>(rays + i);
-        F4 r0 = rp[0], r1 = rp[1];
-        V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
-        st.sp = 0;
-        Closest best;
-        closest_hit(scene, o, d, r0.w, r1.w, st, best, (uint32_t *)nullptr, (uint32_t *)nullptr);
-        HitInfo h;
-        finish_hit(scene, o, d, best, h);
-        F4 *hp = reinterpret_cast<F4 *>(hits + i);
-        F4 h0, h1, h2;
-        h0.x = h.t;
-        h0.y = h.pos.x;
-        h0.z = h.pos.y;
-        h0.w = h.pos.z;
-        h1.x = h.n.x;
-        h1.y = h.n.y;
-        h1.z = h.n.z;
-        h1.w = h.u;
-        h2.x = h.v;
-        h2.y = __builtin_bit_cast(float, h.geom_id);
-        h2.z = __builtin_bit_cast(float, h.prim_id);
-        h2.w = __builtin_bit_cast(float, h.mat_id);
-        hp[0] = h0;
-        hp[1] = h1;
-        hp[2] = h2;
+    const uint64_t waves = (uint64_t)gridDim.x * (BLOCK / 64);
+    const uint64_t wave = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t per_wave = ((n + waves - 1) / waves + 63) / 64 * 64;
+    uint64_t next = wave * per_wave; // wave-uniform
+    const uint64_t end = next + per_wave < n ? next + per_wave : n;
+    bool has_ray = false;
+    uint64_t index = 0;
+    float tnear = 0.0f;
+    V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f);
+    Trav tr;
+    tr.cur = RT_EMPTY;
+    for (;;) {
+        const bool busy = has_ray && tr.cur != RT_EMPTY;
+        const int n_busy = (int)__popcll(__ballot(busy));
+        if (n_busy < 48) {
+            if (has_ray && !busy) {
+                HitInfo h;
+                finish_hit(scene, org, dir, tr.best, h);
+                F4 *hp = reinterpret_cast<F4 *>(hits + index);
+                F4 h0, h1, h2;
+                h0.x = h.t;
+                h0.y = h.pos.x;
+                h0.z = h.pos.y;
+                h0.w = h.pos.z;
+                h1.x = h.n.x;
+                h1.y = h.n.y;
+                h1.z = h.n.z;
+                h1.w = h.u;
+                h2.x = h.v;
+                h2.y = __builtin_bit_cast(float, h.geom_id);
+                h2.z = __builtin_bit_cast(float, h.prim_id);
+                h2.w = __builtin_bit_cast(float, h.mat_id);
+                hp[0] = h0;
+                hp[1] = h1;
+                hp[2] = h2;
+                has_ray = false;
+            }
+            if (next < end) {
+                const unsigned long long nmask = __ballot(!has_ray);
+                const uint64_t i = next + rank_in(nmask);
+                next = next + (uint64_t)__popcll(nmask) < end ? next + (uint64_t)__popcll(nmask) : end;
+                if (!has_ray && i < end) {
+                    const F4 *rp = reinterpret_cast<const F4 *>(rays + i);
+                    const F4 r0 = rp[0], r1 = rp[1];
+                    org = mk(r0.x, r0.y, r0.z);
+                    dir = mk(r1.x, r1.y, r1.z);
+                    tnear = r0.w;
+                    index = i;
+                    st.sp = 0;
+                    trav_begin(scene, org, dir, r1.w, tr);
+                    has_ray = true;
+                }
+            }
+            if (__ballot(has_ray) == 0ull) {
+                if (next >= end) break;
+                continue;
+            }
+        }
+        st.note_depth();
+        const bool at_leaf = has_ray && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
+        const bool at_node = has_ray && tr.cur != RT_EMPTY && !at_leaf;
+        const int n_node = (int)__popcll(__ballot(at_node));
+        const int n_leaf = (int)__popcll(__ballot(at_leaf));
+        if (n_leaf == 0 || (n_node > 0 && n_node >= n_leaf)) {
+            if (at_node) trav_node_step(scene, tnear, tr, st);
+        } else {
+            if (at_leaf) trav_leaf_step(scene, org, dir, tnear, tr, st);
+        }
     }
 }
 
