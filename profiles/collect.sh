@@ -8,6 +8,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1
 OUT=$R/gpurun_out/$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd $R
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.log || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
