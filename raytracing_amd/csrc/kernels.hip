@@ -480,11 +480,29 @@ __global__ __launch_bounds__(BLOCK) void tail_kernel(RenderArgs a, uint32_t dept
         ray_depth = ldp(Q + 10 * H, pos);
     }
     for (uint32_t depth = depth0; depth < a.max_depth; ++depth) {
+        // closest hit of the wave's live rays, in node / record phases like extend_kernel (no refill: the wave's rays
+        // of one bounce start together)
+        Trav tr;
+        tr.cur = RT_EMPTY;
         if (alive) {
             st.sp = 0;
-            st.shallow = false;
-            Closest best;
-            closest_hit(a.scene, org, dir, RT_TNEAR, INFINITY, st, best, (uint32_t *)nullptr, (uint32_t *)nullptr);
+            trav_begin(a.scene, org, dir, INFINITY, tr);
+        }
+        for (;;) {
+            st.note_depth();
+            const bool at_leaf = tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
+            const bool at_node = tr.cur != RT_EMPTY && !at_leaf;
+            const int n_node = (int)__popcll(__ballot(at_node));
+            const int n_leaf = (int)__popcll(__ballot(at_leaf));
+            if (n_node + n_leaf == 0) break;
+            if (n_leaf == 0 || (n_node > 0 && n_node >= n_leaf)) {
+                if (at_node) trav_node_step(a.scene, RT_TNEAR, tr, st);
+            } else {
+                if (at_leaf) trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
+            }
+        }
+        if (alive) {
+            const Closest best = tr.best;
             HitInfo h;
             finish_hit(a.scene, org, dir, best, h);
             VertexOut vo;
