@@ -692,7 +692,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             int lrc = rtk::launch_extend(a, depth, grid, stream);
             if (ev1) (void)hipEventRecord(ev1, stream);
             if (lrc || rtk::launch_shade(a, depth, longest, stream)) {
-                rc = fail(RTMI_ERR_DEVICE, "bounce kernel launch failed");
+                rc = fail(RTMI_ERR_DEVICE, "extend or shade kernel launch failed");
                 break;
             }
             ++launches;

@@ -216,7 +216,7 @@ void hs_intersect(void *p, const Ray *rays, Hit *hits, size_t n) {
     }
 }
 
-// One pixel sample through the same per-vertex steps the bounce kernel runs.  out as in the oracle's
+// One pixel sample through the same per-vertex steps the extend, shade and tail kernels run.  out as in the oracle's
 // orc_render_sample: color 0-2, normal 3-5, position 6-8, albedo 9-11, z, ray_depth, samples.  Returns rays traced.
 static uint32_t render_sample(Scene *s, const CameraView &cam, const Params &prm, uint32_t x, uint32_t y,
                               uint32_t sample, float out[15]) {
