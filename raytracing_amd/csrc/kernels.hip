@@ -1,9 +1,11 @@
 // kernels.hip -- gfx950 kernels of the wavefront path tracer.
 //
 //   intersect_kernel   batch closest hit (Shape::intersection_full for n rays)
-//   extend_kernel      closest hit of every live path's ray (camera rays are generated here at bounce 0)
+//   raygen_kernel      camera rays of every path of a pass
+//   extend_kernel      closest hit of every live path's ray at one bounce (persistent waves, lanes refill themselves)
 //   shade_kernel       scatter / terminate every path from its hit record, compact the survivors into the next
 //                      bounce's queue
+//   tail_kernel        the last few paths of a pass, each run to its end in one launch
 //   accumulate_kernel  adds a pass's samples to the per-pixel accumulators, in sample order
 //   resolve_kernel     accumulators -> the seven output channels
 //
