@@ -130,7 +130,8 @@ def main():
     mesh = getattr(sg, "dragon_mesh", args.scene)
 
     my_tiles = D.partition_tiles(tiler.tile_count(), world, rank)
-    xy = D.tile_pixels(tiler, my_tiles)
+    block = tuple(int(v) for v in os.environ.get("RTMI_BENCH_BLOCK", "8x8").split("x"))
+    xy = D.tile_pixels(tiler, my_tiles, block if block[0] > 0 else None)
     accum = torch.zeros((api.ACCUM_PLANES, xy.shape[0]), dtype=torch.float32, device=dev_t)
     torch.cuda.synchronize()
     film = api.Film(device, xy, accum.data_ptr())

@@ -330,6 +330,12 @@ def test_two_rank_tile_partition_and_gather(oracle, tmp_path):
     parts = [list(D.partition_tiles(tiler.tile_count(), 3, r)) for r in range(3)]
     assert sorted(sum(parts, [])) == list(range(tiler.tile_count()))
     assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    # block order of a tile's pixels: the same pixels, 64 consecutive entries forming an 8 x 8 block where the tile allows
+    blocked = D.tile_pixels(tiler, range(tiler.tile_count()), (8, 8))
+    plain = D.tile_pixels(tiler, range(tiler.tile_count()))
+    assert sorted(map(tuple, blocked.tolist())) == sorted(map(tuple, plain.tolist()))
+    first = blocked[:64]
+    assert first[:, 0].max() - first[:, 0].min() == 7 and first[:, 1].max() - first[:, 1].min() == 7
     # single-rank path of gather_frame (no process group)
     xy = D.tile_pixels(tiler, range(tiler.tile_count()))
     acc, _ = so.render(cam, oracle.make_params(spp=spp), xy)
