@@ -230,6 +230,7 @@ int rtmi_scene_insert_mesh(rtmi_scene *scene, uint32_t material, const float *ve
     if (scene->committed) return fail(RTMI_ERR_STATE, "scene already committed");
     if (material >= scene->materials.size()) return fail(RTMI_ERR_ARG, "unknown material id");
     if (scene->prims.size() + n_triangles >= (1u << 28)) return fail(RTMI_ERR_LIMIT, "more than 2^28 primitives");
+    if (scene->geom_material.size() >= rtd::RT_GEOM_MASK) return fail(RTMI_ERR_LIMIT, "more than 2^24 geometries");
     for (size_t i = 0; i < 3 * n_triangles; ++i)
         if (indices[i] >= n_vertices) return fail(RTMI_ERR_ARG, "vertex index out of range");
     const uint32_t geom = (uint32_t)scene->geom_material.size();
@@ -255,6 +256,7 @@ int rtmi_scene_insert_sphere(rtmi_scene *scene, uint32_t material, const float c
     if (scene->committed) return fail(RTMI_ERR_STATE, "scene already committed");
     if (material >= scene->materials.size()) return fail(RTMI_ERR_ARG, "unknown material id");
     if (scene->prims.size() + 1 >= (1u << 28)) return fail(RTMI_ERR_LIMIT, "more than 2^28 primitives");
+    if (scene->geom_material.size() >= rtd::RT_GEOM_MASK) return fail(RTMI_ERR_LIMIT, "more than 2^24 geometries");
     const uint32_t geom = (uint32_t)scene->geom_material.size();
     scene->geom_material.push_back(material);
     HostPrim p{};
