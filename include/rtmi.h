@@ -105,8 +105,16 @@ typedef struct rtmi_render_params {
     float allowed_error;   /* --allowed-error (executor.rs:244-249): within one call a pixel stops accumulating once
                             * the 95 % confidence error of all three colour channels is below this; <= 0 = off.  The
                             * reference applies it per batch of 32 samples: call once per batch to reproduce that. */
-    uint32_t reserved;
+    uint32_t flags;        /* RTMI_SAMPLER_* | RTMI_FILTER_*; 0 = what the executor builds (executor.rs:217-223) */
 } rtmi_render_params;
+
+/* Pixel samplers (crates/rt/src/sampler.rs:18-112) and filters (crates/rt/src/filter.rs:11-55, radius 0.7) */
+#define RTMI_SAMPLER_STRATIFIED 0x00u
+#define RTMI_SAMPLER_UNIFORM 0x01u
+#define RTMI_SAMPLER_PIXEL_CENTRE 0x02u /* DummyPixelSampler */
+#define RTMI_FILTER_BOX 0x00u
+#define RTMI_FILTER_TRIANGLE 0x10u
+#define RTMI_FILTER_NONE 0x20u /* DummyFilter */
 
 typedef struct rtmi_render_stats {
     uint64_t rays;   /* closest-hit queries traced, bounces included */

@@ -42,7 +42,7 @@ class RenderParams(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
                 ("max_depth", C.c_uint32), ("integrator", C.c_uint32), ("isect_mode", C.c_uint32),
                 ("form", C.c_uint32), ("threads", C.c_uint32), ("seed", C.c_uint64), ("allowed_error", C.c_float),
-                ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32)]
 
 
 class Tile(C.Structure):
@@ -144,8 +144,12 @@ def make_camera(cam):
     return c
 
 
+SAMPLER_STRATIFIED, SAMPLER_UNIFORM, SAMPLER_PIXEL_CENTRE = 0x00, 0x01, 0x02
+FILTER_BOX, FILTER_TRIANGLE, FILTER_NONE = 0x00, 0x10, 0x20
+
+
 def make_params(spp, sample_begin=0, sample_end=None, max_depth=64, integrator=0, isect_mode=ISECT_BVH,
-                form=FORM_ITERATIVE, threads=0, seed=0, allowed_error=0.0):
+                form=FORM_ITERATIVE, threads=0, seed=0, allowed_error=0.0, flags=0):
     p = RenderParams()
     p.spp = spp
     p.sample_begin = sample_begin
@@ -157,6 +161,7 @@ def make_params(spp, sample_begin=0, sample_end=None, max_depth=64, integrator=0
     p.threads = threads
     p.seed = seed
     p.allowed_error = allowed_error or 0.0
+    p.flags = flags
     return p
 
 

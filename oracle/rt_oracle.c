@@ -930,23 +930,42 @@ static v3 quat_mul_vec3(const float q[4], v3 v) {
     return vadd(vadd(vscale(w * w - b2, v), vscale(vdot(v, b) * 2.0f, b)), vscale(w * 2.0f, vcross(b, v)));
 }
 
-/* executor.rs:254-267 (pixel_worker up to camera.ray) + sampler.rs:91-102 + filter.rs:23-32 + camera.rs:62-85 */
+/* filter.rs:40-47 */
+static float sample_tent(float c) { return c <= 0.5f ? sqrtf(2.0f * c) : 1.0f - sqrtf(2.0f - 2.0f * c); }
+
+/* filter.rs:11-55: DummyFilter, BoxFilter, TriangleFilter, radius 0.7 on both axes (executor.rs:221-223) */
+static float filter_offset(uint32_t kind, float p) {
+    if (kind == ORC_FILTER_TRIANGLE) return 0.7f * (2.0f * sample_tent(p) - 1.0f);
+    if (kind == ORC_FILTER_NONE) return p;
+    return lerp_ext(p, -0.7f, 0.7f);
+}
+
+/* executor.rs:254-267 (pixel_worker up to camera.ray) + sampler.rs:18-112 + filter.rs:11-55 + camera.rs:62-85 */
 static void camera_ray(const orc_camera *cam, const orc_render_params *p, uint32_t x, uint32_t y, uint32_t sample,
                        v3 *org, v3 *dir) {
+    const uint32_t sampler = p->flags & 0x03u, filter = p->flags & 0x30u;
     uint32_t n = (uint32_t)floorf(sqrtf((float)p->spp)); /* executor.rs:218 */
     if (n == 0) n = 1;
     uint32_t index = sample % (n * n);
     float cx = (float)(index % n), cy = (float)(index / n);
     float r[4];
     orc_uniform4(p->seed, x, y, sample, 0, r);
-    float px = (cx + r[0]) / (float)n, py = (cy + r[1]) / (float)n;
-    float offx = lerp_ext(px, -0.7f, 0.7f), offy = lerp_ext(py, -0.7f, 0.7f);
+    /* Sampler::sample_2d, twice: pixel position (executor.rs:256), then lens position (camera.rs:70) */
+    float px, py, dx, dy;
+    if (sampler == ORC_SAMPLER_UNIFORM) { /* sampler.rs:54-64 */
+        px = r[0], py = r[1], dx = r[2], dy = r[3];
+    } else if (sampler == ORC_SAMPLER_PIXEL_CENTRE) { /* sampler.rs:18-24 */
+        px = py = dx = dy = 0.5f;
+    } else { /* sampler.rs:91-102 */
+        px = (cx + r[0]) / (float)n, py = (cy + r[1]) / (float)n;
+        dx = (cx + r[2]) / (float)n, dy = (cy + r[3]) / (float)n;
+    }
+    float offx = filter_offset(filter, px), offy = filter_offset(filter, py);
     float cxp = ((float)x + 0.5f) + offx, cyp = ((float)y + 0.5f) + offy;
     float vx = 2.0f * (cxp / (float)cam->width) - 1.0f;
     float vy = 2.0f * (cyp / (float)cam->height) - 1.0f;
     v3 lens = v3_from(cam->lens);
     v3 sensor = V(lens.x + vx * cam->half_width, lens.y + vy * cam->half_height, lens.z + cam->focal_length);
-    float dx = (cx + r[2]) / (float)n, dy = (cy + r[3]) / (float)n;
     float ha = cam->aperture / 2.0f;
     v3 dst = V(lens.x + ha * dx, lens.y + ha * dy, lens.z + ha * 0.0f);
     *org = lens;

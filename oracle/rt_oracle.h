@@ -17,7 +17,7 @@
  *   frame            crates/rt/src/math/transform.rs:63-94
  *   vector helpers   crates/rt/src/math/vec.rs:14-52
  *   camera           crates/rt/src/camera.rs:35-107
- *   sampler, filter  crates/rt/src/sampler.rs:91-112, crates/rt/src/filter.rs:20-33
+ *   sampler, filter  crates/rt/src/sampler.rs:18-112, crates/rt/src/filter.rs:11-55
  *   pixel driver     crates/rt-cli/src/executor.rs:207-270
  *   accumulate       crates/rt/src/renderer.rs:36-96, crates/rt/src/math/stat.rs:10-52,147-183
  *   sRGB             crates/rt/src/color/colorspace.rs:71-80
@@ -115,8 +115,12 @@ typedef struct {
     uint32_t threads;    /* 0 = OpenMP default */
     uint64_t seed;
     float allowed_error; /* --allowed-error; <= 0 or NaN = off (executor.rs:244-249) */
-    uint32_t reserved;
+    uint32_t flags;      /* ORC_SAMPLER_* | ORC_FILTER_*; 0 = StratifiedSampler + BoxFilter (executor.rs:217-223) */
 } orc_render_params;
+
+/* sampler.rs:18-112, filter.rs:11-55 (radius 0.7) */
+enum { ORC_SAMPLER_STRATIFIED = 0x00, ORC_SAMPLER_UNIFORM = 0x01, ORC_SAMPLER_PIXEL_CENTRE = 0x02 };
+enum { ORC_FILTER_BOX = 0x00, ORC_FILTER_TRIANGLE = 0x10, ORC_FILTER_NONE = 0x20 };
 
 /* tile.rs:4-9 */
 typedef struct {

@@ -43,7 +43,7 @@ class TransformPOD(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
                 ("max_depth", C.c_uint32), ("integrator", C.c_uint32), ("samples_per_pass", C.c_uint32),
-                ("seed", C.c_uint64), ("allowed_error", C.c_float), ("reserved", C.c_uint32)]
+                ("seed", C.c_uint64), ("allowed_error", C.c_float), ("flags", C.c_uint32)]
 
 
 class RenderStats(C.Structure):

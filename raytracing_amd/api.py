@@ -329,9 +329,16 @@ class Film:
         return out
 
 
+SAMPLERS = {"stratified": 0x00, "uniform": 0x01, "pixel-centre": 0x02}
+FILTERS = {"box": 0x00, "triangle": 0x10, "none": 0x20}
+
+
 def render(world: CommittedHipScene, film: Film, camera: Camera, spp: int, sample_range=None, max_depth: int = 64,
-           integrator: int = 0, seed: int = 0, samples_per_pass: int = 0, allowed_error: float = 0.0):
-    """rtmi_render: adds samples `sample_range` (default 0..spp) of every film pixel.  Returns the stats dict."""
+           integrator: int = 0, seed: int = 0, samples_per_pass: int = 0, allowed_error: float = 0.0,
+           sampler: str = "stratified", pixel_filter: str = "box"):
+    """rtmi_render: adds samples `sample_range` (default 0..spp) of every film pixel.  Returns the stats dict.
+    `sampler` is "stratified" (what the executor builds), "uniform" or "pixel-centre" (sampler.rs:18-112);
+    `pixel_filter` is "box", "triangle" or "none" (filter.rs:11-55, radius 0.7)."""
     p = _lib.RenderParams()
     p.spp = int(spp)
     rng = sample_range if sample_range is not None else range(0, spp)
@@ -341,6 +348,7 @@ def render(world: CommittedHipScene, film: Film, camera: Camera, spp: int, sampl
     p.samples_per_pass = int(samples_per_pass)
     p.seed = int(seed)
     p.allowed_error = float(allowed_error or 0.0)
+    p.flags = SAMPLERS[sampler] | FILTERS[pixel_filter]
     cam = camera_pod(camera)
     st = _lib.RenderStats()
     check(world._l.rtmi_render(world._h, film._h, C.byref(cam), C.byref(p), C.byref(st)))

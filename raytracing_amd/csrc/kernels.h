@@ -69,6 +69,7 @@ struct RenderArgs {
     float allowed_error;  // > 0: a pixel stops accumulating within this pass once its colour error is below it
     uint32_t sample_base; // first sample index of the pass
     uint32_t strata;      // floor(sqrt(spp))
+    uint32_t flags;       // pixel sampler and filter kinds (rt_device.h RT_SAMPLER_*, RT_FILTER_* << 4)
     uint32_t max_depth;
     uint32_t integrator;
     uint64_t seed;

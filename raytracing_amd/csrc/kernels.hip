@@ -200,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(RenderArgs a) {
     const uint32_t pos = seg * a.seg_cap + i;
     const Entry e = queue_entry(a, 0u, seg, i, nullptr);
     V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 0.0f);
-    if (e.valid) camera_ray(a.camera, a.strata, a.seed, a.pixels[2 * e.pix], a.pixels[2 * e.pix + 1], e.sample, org, dir);
+    if (e.valid) camera_ray(a.camera, a.strata, a.flags, a.seed, a.pixels[2 * e.pix], a.pixels[2 * e.pix + 1], e.sample, org, dir);
     stp(Q + 1 * H, pos, org.x);
     stp(Q + 2 * H, pos, org.y);
     stp(Q + 3 * H, pos, org.z);

@@ -465,22 +465,47 @@ RT_DEV V3 quat_mul_vec3(const float q[4], V3 v) {
     return add(add(scale(w * w - b2, v), scale(dot(v, b) * 2.0f, b)), scale(w * 2.0f, cross(b, v)));
 }
 
-// executor.rs:254-267 + sampler.rs:91-102 + filter.rs:23-32 + camera.rs:62-85.  strata = floor(sqrt(spp)).
-RT_DEV void camera_ray(const CameraView &cam, uint32_t strata, uint64_t seed, uint32_t x, uint32_t y, uint32_t sample,
-                       V3 &org, V3 &dir) {
+// Pixel sampler and filter selection (low byte of the render flags).  The executor only ever builds a
+// StratifiedSampler and a BoxFilter of radius 0.7 (executor.rs:217-223); the other kinds of sampler.rs and filter.rs
+// are offered for completeness.
+constexpr uint32_t RT_SAMPLER_STRATIFIED = 0u, RT_SAMPLER_UNIFORM = 1u, RT_SAMPLER_PIXEL_CENTRE = 2u; // bits 0-1
+constexpr uint32_t RT_FILTER_BOX = 0u, RT_FILTER_TRIANGLE = 1u, RT_FILTER_NONE = 2u;                  // bits 4-5
+
+// filter.rs:40-47
+RT_DEV float sample_tent(float c) { return c <= 0.5f ? sqrtf(2.0f * c) : 1.0f - sqrtf(2.0f - 2.0f * c); }
+
+// filter.rs:11-55 with radius 0.7 on both axes
+RT_DEV float filter_offset(uint32_t kind, float p) {
+    if (kind == RT_FILTER_TRIANGLE) return 0.7f * (2.0f * sample_tent(p) - 1.0f);
+    if (kind == RT_FILTER_NONE) return p;
+    return lerp_ext(p, -0.7f, 0.7f);
+}
+
+// executor.rs:254-267 + sampler.rs:18-112 + filter.rs:11-55 + camera.rs:62-85.  strata = floor(sqrt(spp)).
+RT_DEV void camera_ray(const CameraView &cam, uint32_t strata, uint32_t flags, uint64_t seed, uint32_t x, uint32_t y,
+                       uint32_t sample, V3 &org, V3 &dir) {
+    const uint32_t sampler = flags & 3u, filter = (flags >> 4) & 3u;
     uint32_t n = strata;
     uint32_t index = sample % (n * n);
     float cx = (float)(index % n), cy = (float)(index / n);
     float r[4];
     uniform4(seed, x, y, sample, 0u, r);
-    float px = (cx + r[0]) / (float)n, py = (cy + r[1]) / (float)n;
-    float offx = lerp_ext(px, -0.7f, 0.7f), offy = lerp_ext(py, -0.7f, 0.7f);
+    // Sampler::sample_2d, twice: pixel position, then lens position
+    float px, py, dx, dy;
+    if (sampler == RT_SAMPLER_UNIFORM) {
+        px = r[0], py = r[1], dx = r[2], dy = r[3];
+    } else if (sampler == RT_SAMPLER_PIXEL_CENTRE) {
+        px = py = dx = dy = 0.5f;
+    } else {
+        px = (cx + r[0]) / (float)n, py = (cy + r[1]) / (float)n;
+        dx = (cx + r[2]) / (float)n, dy = (cy + r[3]) / (float)n;
+    }
+    float offx = filter_offset(filter, px), offy = filter_offset(filter, py);
     float cxp = ((float)x + 0.5f) + offx, cyp = ((float)y + 0.5f) + offy;
     float vx = 2.0f * (cxp / (float)cam.width) - 1.0f;
     float vy = 2.0f * (cyp / (float)cam.height) - 1.0f;
     V3 lens = mk(cam.lens[0], cam.lens[1], cam.lens[2]);
     V3 sensor = mk(lens.x + vx * cam.half_width, lens.y + vy * cam.half_height, lens.z + cam.focal_length);
-    float dx = (cx + r[2]) / (float)n, dy = (cy + r[3]) / (float)n;
     float ha = cam.aperture / 2.0f;
     V3 dst = mk(lens.x + ha * dx, lens.y + ha * dy, lens.z + ha * 0.0f);
     org = lens;

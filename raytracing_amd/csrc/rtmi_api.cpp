@@ -531,6 +531,8 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     if (params->sample_end < params->sample_begin) return fail(RTMI_ERR_ARG, "sample range is reversed");
     if (params->spp == 0) return fail(RTMI_ERR_ARG, "spp must be at least 1");
     if (params->integrator > RTMI_INTEGRATOR_RANDOM_WALK) return fail(RTMI_ERR_ARG, "unknown integrator");
+    if ((params->flags & ~0x33u) != 0 || (params->flags & 3u) == 3u || ((params->flags >> 4) & 3u) == 3u)
+        return fail(RTMI_ERR_ARG, "unknown sampler or filter kind in flags");
     if (camera->width == 0 || camera->height == 0) return fail(RTMI_ERR_ARG, "camera has no pixels");
     if (stats) memset(stats, 0, sizeof *stats);
     const uint32_t n_samples = params->sample_end - params->sample_begin;
@@ -617,6 +619,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.n_blocks = (uint32_t)n_blocks;
     a.strata = (uint32_t)floorf(sqrtf((float)params->spp)); // executor.rs:218
     if (a.strata == 0) a.strata = 1;
+    a.flags = params->flags;
     a.max_depth = params->max_depth;
     a.integrator = params->integrator;
     a.seed = params->seed;

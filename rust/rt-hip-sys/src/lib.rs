@@ -27,7 +27,7 @@ pub struct RtmiCamera { pub width: u32, pub height: u32, pub half_width: f32, pu
 #[repr(C)]
 pub struct RtmiTransform { pub translation: [f32; 3], pub scale: [f32; 3], pub rot: [f32; 4] }
 #[repr(C)]
-pub struct RtmiRenderParams { pub spp: u32, pub sample_begin: u32, pub sample_end: u32, pub max_depth: u32, pub integrator: u32, pub samples_per_pass: u32, pub seed: u64 }
+pub struct RtmiRenderParams { pub spp: u32, pub sample_begin: u32, pub sample_end: u32, pub max_depth: u32, pub integrator: u32, pub samples_per_pass: u32, pub seed: u64, pub allowed_error: f32, pub flags: u32 }
 #[repr(C)]
 #[derive(Default)]
 pub struct RtmiRenderStats { pub rays: u64, pub paths: u64, pub passes: u32, pub max_bounces: u32, pub gpu_ms: f32, pub bounce_ms: f32, pub bounce_launches: u32, pub extend_ms: f32, pub tail_rays: u64 }

@@ -52,7 +52,7 @@ struct Params {
     uint32_t spp, sample_begin, sample_end, max_depth, integrator, samples_per_pass;
     uint64_t seed;
     float allowed_error;
-    uint32_t reserved;
+    uint32_t flags;
 };
 
 } // namespace
@@ -225,7 +225,7 @@ static uint32_t render_sample(Scene *s, const CameraView &cam, const Params &prm
     uint32_t strata = (uint32_t)floorf(sqrtf((float)prm.spp));
     if (strata == 0) strata = 1;
     V3 org, dir, beta = mk(1.0f, 1.0f, 1.0f);
-    camera_ray(cam, strata, prm.seed, x, y, sample, org, dir);
+    camera_ray(cam, strata, prm.flags, prm.seed, x, y, sample, org, dir);
     uint32_t rays = 0;
     float ray_depth = 0.0f;
     V3 radiance = mk(0.0f, 0.0f, 0.0f);
@@ -311,7 +311,7 @@ void hs_depth_stats(void *p, const CameraView *cam, const Params *prm, const uin
     for (size_t i = 0; i < npix; ++i)
         for (uint32_t sample = prm->sample_begin; sample < prm->sample_end; ++sample) {
             V3 org, dir, beta = mk(1.0f, 1.0f, 1.0f);
-            camera_ray(*cam, strata, prm->seed, xy[2 * i], xy[2 * i + 1], sample, org, dir);
+            camera_ray(*cam, strata, prm->flags, prm->seed, xy[2 * i], xy[2 * i + 1], sample, org, dir);
             for (uint32_t depth = 0; depth < prm->max_depth; ++depth) {
                 VecStack st;
                 Closest best;

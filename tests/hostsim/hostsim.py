@@ -25,7 +25,7 @@ class CameraView(C.Structure):
 class Params(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
                 ("max_depth", C.c_uint32), ("integrator", C.c_uint32), ("samples_per_pass", C.c_uint32),
-                ("seed", C.c_uint64), ("allowed_error", C.c_float), ("reserved", C.c_uint32)]
+                ("seed", C.c_uint64), ("allowed_error", C.c_float), ("flags", C.c_uint32)]
 
 
 def build():
@@ -92,7 +92,7 @@ def camera_view(cam):
     return c
 
 
-def params(spp, sample_begin=0, sample_end=None, max_depth=64, integrator=0, seed=0):
+def params(spp, sample_begin=0, sample_end=None, max_depth=64, integrator=0, seed=0, flags=0):
     p = Params()
     p.spp = spp
     p.sample_begin = sample_begin
@@ -100,6 +100,7 @@ def params(spp, sample_begin=0, sample_end=None, max_depth=64, integrator=0, see
     p.max_depth = max_depth
     p.integrator = integrator
     p.seed = seed
+    p.flags = flags
     return p
 
 

@@ -186,6 +186,23 @@ def test_depth_limits_seed_and_range(oracle, scene_classes, device):
     assert same_bits(got, want).all()
 
 
+@pytest.mark.parametrize("sampler,pixel_filter,flags", [("uniform", "box", 0x01), ("pixel-centre", "none", 0x22),
+                                                        ("stratified", "triangle", 0x10), ("uniform", "triangle", 0x11)])
+def test_sampler_and_filter_kinds(oracle, scene_classes, device, sampler, pixel_filter, flags):
+    """The samplers and filters the executor never builds (sampler.rs:18-64, filter.rs:11-55): bit-equal to the oracle."""
+    from raytracing_amd import api, types
+    so, world = build_pair(oracle, scene_classes["cornell-box"], device)
+    W, H, spp = 96, 54, 6
+    cam = types.Camera.from_dimensions(W, H)
+    xy = full_frame_xy(W, H)
+    want, want_rays = so.render(cam, oracle.make_params(spp=spp, flags=flags), xy)
+    film = api.Film(device, xy)
+    st = api.render(world, film, cam, spp, sampler=sampler, pixel_filter=pixel_filter)
+    assert st["rays"] == want_rays
+    assert same_bits(film.download(), want).all()
+    film.close()
+
+
 def test_random_walk_integrator(oracle, scene_classes, device):
     """`-i basic`: the oracle keeps the reference's recursion, the GPU carries throughput forward, so the colour sums
     agree to rounding, not bitwise; everything fixed by the first hit is bit-equal."""
@@ -242,6 +259,21 @@ def test_empty_inputs(oracle, scene_classes, device):
     assert empty.download().shape == (22, 0)
     empty.close()
     assert world.intersect(np.zeros(0, dtype=oracle.RAY_DTYPE)).shape == (0,)
+
+
+def test_unknown_sampler_kind_is_an_argument_error(device, scene_classes):
+    from raytracing_amd import _lib, api, types
+    import ctypes as C
+    sg = api.HipScene(device)
+    scene_classes["spheres"].insert_into(sg)
+    world = sg.commit().into_world()
+    film = api.Film(device, full_frame_xy(8, 8))
+    p = _lib.RenderParams()
+    p.spp, p.sample_begin, p.sample_end, p.max_depth, p.flags = 1, 0, 1, 4, 0x03
+    st = _lib.RenderStats()
+    cam = api.camera_pod(types.Camera.from_dimensions(8, 8))
+    assert world._l.rtmi_render(world._h, film._h, C.byref(cam), C.byref(p), C.byref(st)) == -1  # RTMI_ERR_ARG
+    film.close()
 
 
 def test_error_behaviour(device):

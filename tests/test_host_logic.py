@@ -199,6 +199,20 @@ def test_device_code_on_host_matches_oracle(oracle, hostsim, scene_classes, name
     assert sh.stack_high() <= sh.info["stack_need"] <= 128
 
 
+@pytest.mark.parametrize("flags", [0x01, 0x02, 0x10, 0x20, 0x11, 0x22])
+def test_sampler_and_filter_kinds_on_host_match_oracle(oracle, hostsim, scene_classes, flags):
+    so, sh = build_both(oracle, hostsim, scene_classes["cornell-box"])
+    W, H = 48, 27
+    from raytracing_amd import types
+    cam = types.Camera.from_dimensions(W, H)
+    xy = full_frame_xy(W, H)
+    acc_o, _ = so.render(cam, oracle.make_params(spp=4, flags=flags), xy)
+    acc_h, _ = sh.render(cam, hostsim.params(spp=4, flags=flags), xy)
+    assert same_bits(acc_o, acc_h).all()
+    base, _ = so.render(cam, oracle.make_params(spp=4), xy)
+    assert not same_bits(acc_o, base).all()
+
+
 def test_bvh_finds_every_primitive(oracle, hostsim):
     """Random triangles: a ray aimed at each triangle's centroid from just in front of it must report that triangle
     (or a nearer one the brute-force oracle agrees on)."""

@@ -236,6 +236,42 @@ def test_camera_rays(oracle):
         assert -0.7 + 1.4 * cy / 4 - 1e-3 <= py <= -0.7 + 1.4 * (cy + 1) / 4 + 1e-3
 
 
+def test_other_samplers_and_filters(oracle):
+    """sampler.rs:18-64 and filter.rs:11-55: the kinds the executor never builds.  Pixel offsets are recovered from
+    the ray direction (pinhole camera) and checked against the closed forms evaluated from the same uniforms."""
+    from raytracing_amd import types
+    W, H = 1920, 1080
+    cam = types.Camera.from_dimensions(W, H)
+    hw, hh = cam.viewport_half_width, cam.viewport_half_height
+    so = oracle.OracleScene()
+
+    def offsets(flags, sample, spp=16):
+        d = so.camera_rays(cam, oracle.make_params(spp=spp, flags=flags), [[100, 50]], sample)["dir"][0].astype(np.float64)
+        return (-(d[0] / -d[2]) / hw + 1) * W / 2 - 100.5, (-(d[1] / -d[2]) / hh + 1) * H / 2 - 50.5
+
+    def tent(c):
+        return math.sqrt(2 * c) if c <= 0.5 else 1 - math.sqrt(2 - 2 * c)
+
+    for s in range(8):
+        u = oracle.uniform4(0, 100, 50, s, 0)
+        # DummyPixelSampler: always the cell centre, whatever the filter makes of 0.5
+        assert np.allclose(offsets(oracle.SAMPLER_PIXEL_CENTRE | oracle.FILTER_BOX, s), (0.0, 0.0), atol=2e-3)
+        assert np.allclose(offsets(oracle.SAMPLER_PIXEL_CENTRE | oracle.FILTER_NONE, s), (0.5, 0.5), atol=2e-3)
+        # the reference's tent maps 0.5 to 1 (its own comment: "this seems wrong"), i.e. to the +radius edge
+        assert np.allclose(offsets(oracle.SAMPLER_PIXEL_CENTRE | oracle.FILTER_TRIANGLE, s), (0.7, 0.7), atol=2e-3)
+        # UniformSampler: the two uniforms as they come, no strata
+        assert np.allclose(offsets(oracle.SAMPLER_UNIFORM | oracle.FILTER_NONE, s), (u[0], u[1]), atol=2e-3)
+        assert np.allclose(offsets(oracle.SAMPLER_UNIFORM | oracle.FILTER_BOX, s),
+                           (-0.7 + 1.4 * u[0], -0.7 + 1.4 * u[1]), atol=2e-3)
+        # TriangleFilter as written in the reference ("this seems wrong" and all)
+        assert np.allclose(offsets(oracle.SAMPLER_UNIFORM | oracle.FILTER_TRIANGLE, s),
+                           (0.7 * (2 * tent(u[0]) - 1), 0.7 * (2 * tent(u[1]) - 1)), atol=2e-3)
+    # the default is the stratified sampler with the box filter
+    assert np.array_equal(so.camera_rays(cam, oracle.make_params(spp=16), [[7, 9]], 5),
+                          so.camera_rays(cam, oracle.make_params(spp=16, flags=oracle.SAMPLER_STRATIFIED | oracle.FILTER_BOX),
+                                         [[7, 9]], 5))
+
+
 def test_tiles(oracle):
     from raytracing_amd import _lib, api
     L = _lib.load()
