@@ -1128,6 +1128,51 @@ static ray_result random_walk(path_ctx *c, v3 org, v3 dir, float tfar, uint32_t 
     return out;
 }
 
+/* randomwalk.rs:25-68 unrolled front to back like path_tracer_iterative: no material of the reference both emits and
+ * scatters (EmitBxDF::f is zero, every other le() is zero), so the one radiance term a walk collects is weighted by the
+ * carried throughput once.  Differs from the recursion only in the association of the f32 products. */
+static ray_result random_walk_iterative(path_ctx *c, v3 org, v3 dir) {
+    ray_result out = RAY_RESULT_DEFAULT;
+    uint32_t max_depth = c->p->max_depth;
+    if (max_depth == 0) return out;
+    v3 beta = V(1.0f, 1.0f, 1.0f);
+    out.samples = 1;
+    for (uint32_t depth = 0;; ++depth) {
+        if (depth == max_depth) {
+            out.color = vmul(beta, V(0.0f, 0.0f, 0.0f));
+            break;
+        }
+        orc_hit h;
+        c->rays++;
+        if (!intersection_full(c->s, org, dir, 0.00001f, ORC_INF, (int)c->p->isect_mode, &h)) {
+            out.color = vmul(beta, V(0.5f, 0.3f, 1.0f));
+            break;
+        }
+        const orc_material *m = &c->s->materials[h.mat_id];
+        v3 n = v3_from(h.n);
+        float u[4];
+        orc_uniform4(c->p->seed, c->x, c->y, c->sample, 1 + depth, u);
+        v3 wi = uniform_unit_sphere3(u[0], u[1]);
+        v3 f = bsdf_f(m, n, vneg(dir), wi);
+        if (depth == 0) {
+            out.normal = n;
+            out.position = v3_from(h.pos);
+            out.albedo = f;
+            out.z = h.t;
+            out.ray_depth = 0.0f + h.t; /* randomwalk.rs:65: the first hit's t only */
+        }
+        v3 fcos = vscale(fabsf(vdot(n, wi)), f);
+        if (!(fabsf(vmax_element(fcos)) != 0.0f)) {
+            out.color = vmul(beta, material_le(m));
+            break;
+        }
+        beta = vmul(beta, vscale(ORC_FRAC_1_PI / 4.0f, fcos));
+        org = v3_from(h.pos);
+        dir = wi;
+    }
+    return out;
+}
+
 static ray_result render_one(const orc_scene *s, const orc_camera *cam, const orc_render_params *p, uint32_t x,
                              uint32_t y, uint32_t sample, uint32_t *rays) {
     path_ctx c;
@@ -1141,7 +1186,7 @@ static ray_result render_one(const orc_scene *s, const orc_camera *cam, const or
     camera_ray(cam, p, x, y, sample, &org, &dir);
     ray_result r;
     if (p->integrator == ORC_INTEGRATOR_RANDOM_WALK)
-        r = random_walk(&c, org, dir, ORC_INF, 0);
+        r = p->form == ORC_FORM_RECURSIVE ? random_walk(&c, org, dir, ORC_INF, 0) : random_walk_iterative(&c, org, dir);
     else if (p->form == ORC_FORM_RECURSIVE)
         r = path_tracer_recursive(&c, org, dir, ORC_INF, 0);
     else

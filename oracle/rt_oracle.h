@@ -111,7 +111,7 @@ typedef struct {
     uint32_t max_depth;
     uint32_t integrator;
     uint32_t isect_mode; /* ORC_ISECT_* */
-    uint32_t form;       /* ORC_FORM_* (path tracer only) */
+    uint32_t form;       /* ORC_FORM_* */
     uint32_t threads;    /* 0 = OpenMP default */
     uint64_t seed;
     float allowed_error; /* --allowed-error; <= 0 or NaN = off (executor.rs:244-249) */

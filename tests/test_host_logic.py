@@ -199,6 +199,17 @@ def test_device_code_on_host_matches_oracle(oracle, hostsim, scene_classes, name
     assert sh.stack_high() <= sh.info["stack_need"] <= 128
 
 
+def test_random_walk_on_host_matches_oracle(oracle, hostsim, scene_classes):
+    """`-i basic`: the device code's random walk, built for the host, against the oracle's front-to-back walk."""
+    from raytracing_amd import types
+    so, sh = build_both(oracle, hostsim, scene_classes["cornell-box"])
+    cam = types.Camera.from_dimensions(48, 27)
+    xy = full_frame_xy(48, 27)
+    acc_o, rays_o = so.render(cam, oracle.make_params(spp=4, max_depth=8, integrator=1), xy)
+    acc_h, rays_h = sh.render(cam, hostsim.params(spp=4, max_depth=8, integrator=1), xy)
+    assert rays_o == rays_h and same_bits(acc_o, acc_h).all()
+
+
 @pytest.mark.parametrize("flags", [0x01, 0x02, 0x10, 0x20, 0x11, 0x22])
 def test_sampler_and_filter_kinds_on_host_match_oracle(oracle, hostsim, scene_classes, flags):
     so, sh = build_both(oracle, hostsim, scene_classes["cornell-box"])

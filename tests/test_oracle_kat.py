@@ -331,6 +331,13 @@ def test_recursive_and_front_to_back_forms_agree(oracle):
         a, _ = so.render_sample(cam, oracle.make_params(spp=8, form=oracle.FORM_ITERATIVE), x, y, s)
         b, _ = so.render_sample(cam, oracle.make_params(spp=8, form=oracle.FORM_RECURSIVE), x, y, s)
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7)
+    # the random walk (randomwalk.rs:25-68, `-i basic`) likewise; its ray_depth is the first hit's t in both forms
+    it, rays_it = so.render(cam, oracle.make_params(spp=8, max_depth=8, integrator=1, form=oracle.FORM_ITERATIVE), xy)
+    rec, rays_rec = so.render(cam, oracle.make_params(spp=8, max_depth=8, integrator=1, form=oracle.FORM_RECURSIVE), xy)
+    assert rays_it == rays_rec
+    assert same_bits(it[10:22], rec[10:22]).all()
+    np.testing.assert_allclose(it[0:10], rec[0:10], rtol=2e-5, atol=1e-7)
+    assert it[0:3].sum() > 0
 
 
 def test_brute_force_equals_bvh(oracle, scene_classes):
