@@ -22,8 +22,10 @@ namespace rtk {
 
 // Per-lane traversal stack: the first LDS_STACK entries live in LDS, deeper ones (rare: the tree's worst case is far
 // above the typical depth) spill to a per-thread column of a global buffer sized from the committed tree.
+typedef __attribute__((address_space(3))) uint32_t lds_u32; // typed LDS: accesses stay ds_read / ds_write
+
 struct LaneStack {
-    uint32_t *col;   // &lds[thread of block]; entry e is at col[e * BLOCK]
+    lds_u32 *col;    // &lds[thread of block]; entry e is at col[e * BLOCK]
     uint32_t *spill; // wave-uniform base; entry LDS_STACK + e of a thread is at spill[e * threads + global thread]
     int sp;
     bool shallow; // wave-uniform: no lane of the wave is within 4 entries of the LDS part's end (see note_depth)
@@ -50,7 +52,7 @@ struct LaneStack {
 
 __device__ __forceinline__ LaneStack make_stack(uint32_t *lds, uint32_t *spill) {
     LaneStack st;
-    st.col = lds + threadIdx.x;
+    st.col = (lds_u32 *)lds + threadIdx.x;
     st.spill = spill;
     st.sp = 0;
     st.shallow = false;
