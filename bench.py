@@ -129,7 +129,10 @@ def main():
     info = world_scene.info()
     mesh = getattr(sg, "dragon_mesh", args.scene)
 
-    my_tiles = D.partition_tiles(tiler.tile_count(), world, rank)
+    # RTMI_BENCH_SHARE=N: render only the share of tiles one rank of an N-rank job would own (scaling rehearsal on 1 GPU)
+    share = int(os.environ.get("RTMI_BENCH_SHARE", "0"))
+    my_tiles = D.partition_tiles(tiler.tile_count(), share, 0) if share > 1 and world == 1 else \
+        D.partition_tiles(tiler.tile_count(), world, rank)
     block = tuple(int(v) for v in os.environ.get("RTMI_BENCH_BLOCK", "8x8").split("x"))
     xy = D.tile_pixels(tiler, my_tiles, block if block[0] > 0 else None)
     accum = torch.zeros((api.ACCUM_PLANES, xy.shape[0]), dtype=torch.float32, device=dev_t)
