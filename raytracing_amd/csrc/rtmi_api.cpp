@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -35,6 +36,20 @@ int fail(int code, const std::string &msg) {
         if (e_ != hipSuccess)                                                                           \
             return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
     } while (0)
+
+// HIP events of one call, destroyed on every way out of it.
+struct EventPool {
+    std::vector<hipEvent_t> all;
+    hipEvent_t get() {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        all.push_back(e);
+        return e;
+    }
+    ~EventPool() {
+        for (hipEvent_t e : all) (void)hipEventDestroy(e);
+    }
+};
 
 } // namespace
 
@@ -633,12 +648,13 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.spill = scene->d_spill;
     const uint32_t full_grid = scene->grid_blocks;
 
-    hipEvent_t ev_begin, ev_end;
-    HIP_TRY(hipEventCreate(&ev_begin));
-    HIP_TRY(hipEventCreate(&ev_end));
+    EventPool events;
+    hipEvent_t ev_begin = events.get(), ev_end = events.get();
     std::vector<hipEvent_t> ev_extend; // pairs
     std::vector<hipEvent_t> ev_pass(2 * (size_t)n_passes);
-    for (auto &e : ev_pass) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : ev_pass) e = events.get();
+    if (!ev_begin || !ev_end || std::find(ev_pass.begin(), ev_pass.end(), nullptr) != ev_pass.end())
+        return fail(RTMI_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(ev_begin, stream));
     int rc = RTMI_OK;
     uint32_t sample = params->sample_begin;
@@ -688,14 +704,14 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             const uint64_t per_wave = entries / ((uint64_t)grid * waves_per_block * rtk::SEGMENTS) / 8;
             a.claim = 64u * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, per_wave / 64));
             // events around the traversal launch only: its time is what the roofline of the dominant kernel needs
-            hipEvent_t ev0 = nullptr, ev1 = nullptr;
-            if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) {
+            hipEvent_t ev0 = events.get(), ev1 = events.get();
+            if (ev0 && ev1) {
                 ev_extend.push_back(ev0);
                 ev_extend.push_back(ev1);
                 (void)hipEventRecord(ev0, stream);
             }
             int lrc = rtk::launch_extend(a, depth, grid, stream);
-            if (ev1) (void)hipEventRecord(ev1, stream);
+            if (ev0 && ev1) (void)hipEventRecord(ev1, stream);
             if (lrc || rtk::launch_shade(a, depth, longest, stream)) {
                 rc = fail(RTMI_ERR_DEVICE, "extend or shade kernel launch failed");
                 break;
@@ -774,10 +790,6 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->gpu_ms = ms;
     }
-    for (auto &ev : ev_extend) (void)hipEventDestroy(ev);
-    (void)hipEventDestroy(ev_begin);
-    (void)hipEventDestroy(ev_end);
-    for (auto &ev : ev_pass) (void)hipEventDestroy(ev);
     return rc;
 }
 
