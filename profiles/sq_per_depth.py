@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Per-launch SQ counters of one kernel from the output of profiles/pmc_sq.sh or pmc_passes.sh.
+
+usage: sq_per_depth.py <dir under gpurun_out> [kernel name part, default extend_kernel]
+valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); lane_util = SQ_THREAD_CYCLES_VALU /
+(SQ_ACTIVE_INST_VALU x 64)."""
 import csv,glob,sys
 from collections import defaultdict
 root=sys.argv[1]; kern=sys.argv[2] if len(sys.argv)>2 else 'extend_kernel'
