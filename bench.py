@@ -214,6 +214,9 @@ def main():
                         traffic = tj[key]["hbm_bytes_per_launch"]
                 except Exception:
                     traffic = None
+            scene_bytes = info["node_bytes"] + info["prim_bytes"]
+            residency = "L2 (4 MB per XCD)" if scene_bytes < 4e6 else \
+                "infinity cache (256 MB)" if scene_bytes < 128e6 else "hbm + infinity cache"
             roofline = {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -233,9 +236,11 @@ def main():
                 "nodes_per_ray": nodes / max(extend_rays, 1),
                 "records_per_ray": records / max(extend_rays, 1),
                 "bytes_per_ray": alg_bytes / max(extend_rays, 1),
-                "note": "scene (%.0f MB nodes + %.0f MB primitive records) exceeds the 32 MB of L2 and about fills the "
-                        "256 MB Infinity Cache; fetches are 64-B node / 64-B record gathers"
-                        % (info["node_bytes"] / 1e6, info["prim_bytes"] / 1e6),
+                "scene_resident_in": residency,
+                "note": "scene: %.1f MB nodes + %.1f MB primitive records (64-B node / 64-B record gathers), resident in %s%s"
+                        % (info["node_bytes"] / 1e6, info["prim_bytes"] / 1e6, residency,
+                           "" if residency == "hbm + infinity cache" else
+                           ": the kernel is not HBM-bound on this scene and the fraction of HBM peak says little"),
             }
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
