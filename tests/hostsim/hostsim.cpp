@@ -453,3 +453,84 @@ extern "C" void hs_wave_sim(void *p, const Ray *rays, size_t n, int policy, int 
         }
     }
 }
+
+
+// Variant of the model above with two rays per lane: every step a lane advances whichever of its two rays waits for the
+// phase the wave runs.  out as hs_wave_sim.  cost[3] is charged per iteration and should include the selects that pick
+// the active ray's registers.
+extern "C" void hs_wave_sim2(void *p, const Ray *rays, size_t n, int refill_below, const double cost[4], double out[8]) {
+    Scene *s = (Scene *)p;
+    const double c_node = cost[0], c_leaf = cost[1], c_refill = cost[2], c_iter = cost[3];
+    struct Slot {
+        bool has = false;
+        V3 o, d;
+        Trav tr;
+        VecStack st;
+    };
+    for (int k = 0; k < 8; ++k) out[k] = 0.0;
+    size_t next = 0;
+    while (next < n) {
+        const size_t wave_end = std::min(n, next + 8192);
+        std::vector<Slot> L(128);
+        for (;;) {
+            int n_busy = 0;
+            for (auto &l : L)
+                if (l.has && l.tr.cur != RT_EMPTY) ++n_busy;
+            if (n_busy < refill_below || n_busy == 0) {
+                bool any = false;
+                for (auto &l : L) {
+                    if (l.has && l.tr.cur == RT_EMPTY) l.has = false, any = true;
+                    if (!l.has && next < wave_end) {
+                        const Ray &r = rays[next++];
+                        l.o = mk(r.org[0], r.org[1], r.org[2]);
+                        l.d = mk(r.dir[0], r.dir[1], r.dir[2]);
+                        l.st = VecStack();
+                        trav_begin(s->view, l.o, l.d, INFINITY, l.tr);
+                        l.has = true;
+                        any = true;
+                    }
+                }
+                if (any) out[0] += 64.0 * c_refill, out[6] += 1.0;
+                n_busy = 0;
+                for (auto &l : L)
+                    if (l.has && l.tr.cur != RT_EMPTY) ++n_busy;
+                if (n_busy == 0) {
+                    if (next >= wave_end) break;
+                    continue;
+                }
+            }
+            out[0] += 64.0 * c_iter;
+            int lanes_node = 0, lanes_leaf = 0;
+            auto at_node = [](const Slot &l) { return l.has && l.tr.cur != RT_EMPTY && !(l.tr.cur & RT_LEAF); };
+            auto at_leaf = [](const Slot &l) { return l.has && l.tr.cur != RT_EMPTY && (l.tr.cur & RT_LEAF); };
+            for (int l = 0; l < 64; ++l) {
+                if (at_node(L[l]) || at_node(L[l + 64])) ++lanes_node;
+                if (at_leaf(L[l]) || at_leaf(L[l + 64])) ++lanes_leaf;
+            }
+            const bool node_phase = lanes_leaf == 0 || (lanes_node > 0 && lanes_node >= lanes_leaf);
+            if (node_phase) {
+                out[0] += 64.0 * c_node;
+                out[4] += 1.0;
+                for (int l = 0; l < 64; ++l) {
+                    Slot &x = at_node(L[l]) ? L[l] : L[l + 64];
+                    if (at_node(x)) {
+                        trav_node_step(s->view, RT_TNEAR, x.tr, x.st);
+                        out[1] += c_node;
+                        out[2] += 1.0;
+                    }
+                }
+            } else {
+                out[0] += 64.0 * c_leaf;
+                out[5] += 1.0;
+                for (int l = 0; l < 64; ++l) {
+                    Slot &x = at_leaf(L[l]) ? L[l] : L[l + 64];
+                    if (at_leaf(x)) {
+                        trav_leaf_step(s->view, x.o, x.d, RT_TNEAR, x.tr, x.st);
+                        out[1] += c_leaf;
+                        out[3] += 1.0;
+                    }
+                }
+            }
+        }
+    }
+}
