@@ -399,6 +399,35 @@ def test_deep_traversal_stack_spills(oracle, device):
     check_hits(world.intersect(rays), so.intersect(rays, oracle.ISECT_BRUTE))
 
 
+@pytest.mark.parametrize("tail_rays", ["0", "1000000"])
+def test_deep_traversal_stack_in_render(oracle, device, monkeypatch, tail_rays):
+    """The same kind of soup, diffuse, rendered from inside: the spill path of the per-bounce traversal kernel
+    (RTMI_TAIL_RAYS=0) and of the tail kernel, against the oracle's accumulators."""
+    from raytracing_amd import api, types
+    monkeypatch.setenv("RTMI_TAIL_RAYS", tail_rays)
+    rng = np.random.default_rng(6)
+    n = 30000
+    c = rng.uniform(-1, 1, (n, 3)) + np.array([0, 0, -2.5])
+    v = (c[:, None, :] + rng.normal(scale=1.5, size=(n, 3, 3))).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    so, sg = oracle.OracleScene(), api.HipScene(device)
+    for s in (so, sg):
+        m = s.insert_material(types.MaterialDescriptor("grey", types.DiffuseBxDF((0.8, 0.8, 0.8))))
+        s.insert_mesh(m, v.reshape(-1, 3), idx)
+    so.commit()
+    world = sg.commit().into_world()
+    assert world.info()["stack_need"] > 24
+    W, H, spp = 48, 27, 2
+    cam = types.Camera.from_dimensions(W, H)
+    xy = full_frame_xy(W, H)
+    want, want_rays = so.render(cam, oracle.make_params(spp=spp, max_depth=6), xy)
+    film = api.Film(device, xy)
+    st = api.render(world, film, cam, spp, max_depth=6)
+    assert st["rays"] == want_rays and st["rays"] > 3 * W * H * spp
+    assert same_bits(film.download(), want).all()
+    film.close()
+
+
 def test_allowed_error_adaptive_sampling(oracle, scene_classes, device):
     """--allowed-error: within a batch a pixel stops accumulating once all three channels are precise
     (executor.rs:244-249); batches of 32 as the reference's SampleCounter.  Sky pixels (zero variance) stop at 16
