@@ -23,7 +23,7 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-# algorithmic bytes of the traversal kernel (see DESIGN.md "Kernels"): one 64-B BVH4 node per node visit, one 64-B
+# algorithmic bytes of the traversal kernel: one 64-B BVH4 node per node visit, one 64-B
 # primitive record (up to two triangles) per leaf visit, and per ray the ray read (origin + direction, 24 B) and the
 # hit record written (t, Ng, geometry word, 20 B)
 NODE_BYTES = 64
