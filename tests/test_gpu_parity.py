@@ -300,7 +300,7 @@ def test_error_behaviour(device):
 
 
 def test_full_size_properties(oracle, scene_classes, device):
-    """Bunny 1920x1080 at 20 spp (a BASELINE configuration): properties that hold without the oracle.
+    """Bunny 1920x1080 at 20 spp (one of the benchmark configurations): properties that hold without the oracle.
     - determinism: two renders are bit-identical;
     - RaySeries::merge: samples 0..8 plus samples 8..20 equal 0..20 in every plane that is a plain sum;
     - tiles: rendering the interleaved halves of the tile list separately reproduces the whole frame bit for bit;
