@@ -17,7 +17,7 @@ for f in glob.glob(root+'/*/*/*counter_collection.csv'):
         v.sort(); data[c]=[x for _,x in v]
 D=data
 print('depth  Mcyc  valu_busy  lane_util valu_insts(G) salu(G) wait_any wait_inst')
-for i in range(8):
+for i in range(min(21, len(D["GRBM_GUI_ACTIVE"]))):
     cyc=D['GRBM_GUI_ACTIVE'][i]/8
     busy=D['SQ_ACTIVE_INST_VALU'][i]*4/(cyc*1024)
     util=D['SQ_THREAD_CYCLES_VALU'][i]/(D['SQ_ACTIVE_INST_VALU'][i]*64)
