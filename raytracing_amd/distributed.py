@@ -46,13 +46,16 @@ class FrameGatherer:
     the padded exchange buffers.  Per frame it costs one gather of [ACCUM_PLANES, n_max] floats and, on rank 0, one
     index_copy per rank.  Without an initialised process group this is the single-rank case."""
 
-    def __init__(self, xy_local: np.ndarray, width: int, height: int, device, offset=(0, 0), group=None):
+    def __init__(self, xy_local: np.ndarray, width: int, height: int, device, offset=(0, 0), group=None,
+                 always_collective=False):
         self.width, self.height, self.group = width, height, group
         self.device = torch.device(device)
         lin = (xy_local[:, 1].astype(np.int64) - offset[1]) * width + (xy_local[:, 0].astype(np.int64) - offset[0])
         self.lin_local = torch.from_numpy(lin).to(self.device)
         self.n_local = int(xy_local.shape[0])
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # always_collective: go through the collectives even in a group of one (exercises the backend in tests)
+        self.distributed = dist.is_available() and dist.is_initialized() and \
+            (dist.get_world_size(group) > 1 or always_collective)
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.world = dist.get_world_size(group) if self.distributed else 1
         if not self.distributed:

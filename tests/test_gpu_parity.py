@@ -490,3 +490,46 @@ def test_handles_may_be_destroyed_in_any_order(device):
     assert st["paths"] == 2 * 16 * 9
     film.close()
     sg.close()
+
+
+_RCCL_GATHER = r"""
+import socket, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+from raytracing_amd import api
+from raytracing_amd import distributed as D
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+W, H = 70, 50
+tiler = api.Tiler(0, 0, W, H, 32, 32)
+xy = D.tile_pixels(tiler, range(tiler.tile_count()), (8, 8))
+acc = torch.arange(api.ACCUM_PLANES * xy.shape[0], dtype=torch.float32, device="cuda").reshape(api.ACCUM_PLANES, -1)
+want = D.FrameGatherer(xy, W, H, "cuda").gather(acc)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% port, rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+g = D.FrameGatherer(xy, W, H, "cuda", always_collective=True)
+assert g.distributed
+buf = torch.zeros_like(want)
+got = g.gather(acc * 2.0, buf)
+got = g.gather(acc, buf)
+t = torch.tensor([3, 4], dtype=torch.int64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.SUM)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(got, want) and t.tolist() == [3, 4]
+dist.destroy_process_group()
+print("rccl gather ok")
+"""
+
+
+def test_frame_gather_over_rccl():
+    """The collectives bench.py uses for N > 1 (all_gather, gather, all_reduce, barrier) on GPU tensors over the nccl
+    (RCCL) backend, in a group of one and in a process of their own: the gathered frame must equal the local scatter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_GATHER % root], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and "rccl gather ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
