@@ -16,7 +16,11 @@
  *     errors, embree.rs:190-248, and returns anyhow::Result from commit, embree.rs:63-69; a binding maps non-zero
  *     to those.)
  *   - insert_* / load_obj / commit on one scene must not run concurrently (the reference takes &mut self).
- *     Queries and renders on a committed scene may be issued from several threads; they serialise per device.
+ *     Queries and renders on a committed scene may be issued from several threads (Shape is Sync + Send,
+ *     shape/mod.rs:3): rtmi_intersect, rtmi_render and the film calls serialise per device on the library's stream;
+ *     rtmi_intersect_device launches on the caller's stream and may overlap with anything.
+ *   - Every entry point makes its device current while it runs and restores the calling thread's current HIP device
+ *     before it returns.
  *   - A scene is immutable once committed (the reference enforces it by borrow, embree.rs:81-84); inserting
  *     after commit returns RTMI_ERR_STATE.
  */
@@ -39,6 +43,7 @@ extern "C" {
 #define RTMI_ERR_LIMIT (-6)  /* a size exceeds what the kernels support */
 
 #define RTMI_INVALID_ID 0xFFFFFFFFu
+#define RTMI_MAX_RAY_DEPTH 4096u /* largest rtmi_render_params.max_depth (the reference's default is 64) */
 
 /* BxDF kinds: crates/rt/src/material/mod.rs:98-101 (Diffuse), :133-137 (Dielectric), :315-318 (ThinDielectric),
  * :369-372 (Emit). */
@@ -104,7 +109,10 @@ typedef struct rtmi_render_params {
     uint64_t seed;         /* --seed */
     float allowed_error;   /* --allowed-error (executor.rs:244-249): within one call a pixel stops accumulating once
                             * the 95 % confidence error of all three colour channels is below this; <= 0 = off.  The
-                            * reference applies it per batch of 32 samples: call once per batch to reproduce that. */
+                            * reference applies it per batch of 32 samples: call once per batch to reproduce that.
+                            * However many passes the call is split into, a stopped pixel stays stopped until the call
+                            * returns, and later passes no longer trace it (with samples_per_pass = 0 such a call uses
+                            * passes of at most 8 samples). */
     uint32_t flags;        /* RTMI_SAMPLER_* | RTMI_FILTER_*; 0 = what the executor builds (executor.rs:217-223) */
 } rtmi_render_params;
 
@@ -195,9 +203,18 @@ int rtmi_scene_get_info(const rtmi_scene *scene, rtmi_scene_info *out);
 int rtmi_scene_geometry_material(const rtmi_scene *scene, uint32_t geom, uint32_t *out_material);
 
 /* Shape::intersection_full (shape/mod.rs:4, embree.rs:101-140) for n rays at once: closest hit in
- * (tnear, tfar].  Host arrays; the rays are copied to the GPU, traced there and the hits copied back. */
+ * (tnear, tfar].  Host arrays; the rays are copied to the GPU, traced there and the hits copied back, through staging
+ * buffers the scene keeps between calls (a call allocates only when n exceeds every earlier n).
+ * Ray origins must lie within 16 times the scene's largest |coordinate| of the coordinate origin on every axis: the
+ * tree's culling boxes are padded for the rounding of slab distances up to that range, and beyond it a hit could be
+ * culled.  A ray outside the range makes the call fail with RTMI_ERR_ARG (start such a ray nearer: move its origin
+ * along the direction and shorten tfar). */
 int rtmi_intersect(rtmi_scene *scene, const rtmi_ray *rays, rtmi_hit *hits, size_t n);
-/* Same with device-resident arrays, asynchronous on hip_stream (a hipStream_t; NULL = the default stream). */
+/* Same with device-resident arrays, asynchronous on hip_stream (a hipStream_t; NULL = the default stream); the
+ * origin range above is the caller's to keep (the rays are not inspected).  Launches on different streams may overlap
+ * each other and renders: on a tree deeper than the kernels' on-chip stack (rtmi_scene_info.stack_need > 24) each
+ * launch takes one of four stack-overflow buffers, created on first use, and a fifth concurrent launch waits on its
+ * stream for the first to finish. */
 int rtmi_intersect_device(rtmi_scene *scene, const rtmi_ray *d_rays, rtmi_hit *d_hits, size_t n, void *hip_stream);
 
 /* The per-pixel accumulators the executor keeps (Dispatcher::tiles_data, executor.rs:177-205; RaySeries,

@@ -58,6 +58,9 @@ struct RenderArgs {
     uint32_t *work;         // work[(d * SEGMENTS + x) * COUNTER_STRIDE] = next unclaimed position of that queue; zeroed
     uint32_t *spill;        // traversal stack overflow: (stack_need - LDS_STACK) entries per launched thread
     uint32_t *visit_counters; // optional: [0] node visits, [1] primitive tests (64-bit pairs lo/hi), may be null
+    uint32_t *pixel_done;     // optional: pixel_done[i] != 0 = pixel i is precise enough and takes no more samples in
+                              // this call (its paths are neither generated nor accumulated); pixel_done[n_pixels]
+                              // counts them.  Written by accumulate_kernel only.  May be null.
     uint32_t n_pixels;
     uint32_t n_blocks;    // ceil(n_pixels / PIXEL_BLOCK)
     uint32_t samples;     // samples of each pixel in this pass

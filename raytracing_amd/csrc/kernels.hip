@@ -172,7 +172,7 @@ __device__ __forceinline__ Entry queue_entry(const RenderArgs &a, uint32_t depth
         e.pix = blk * (uint32_t)PIXEL_BLOCK + rem % (uint32_t)PIXEL_BLOCK;
         e.pid = blk * per_block + rem;
         e.sample = a.sample_base + rem / (uint32_t)PIXEL_BLOCK;
-        e.valid = e.pix < a.n_pixels;
+        e.valid = e.pix < a.n_pixels && !(a.pixel_done != nullptr && a.pixel_done[e.pix] != 0u);
     } else {
         e.pid = __builtin_bit_cast(uint32_t, q_in[i]);
         const uint32_t blk = e.pid / per_block, rem = e.pid - blk * per_block;
@@ -192,7 +192,8 @@ __device__ __forceinline__ uint32_t segment_entries(const RenderArgs &a, uint32_
 }
 
 // Camera rays of every path of a pass, in the implicit queue order of bounce 0, into the bounce's payload planes.
-// Padding entries (pixels past n_pixels) get a zero direction, which no camera ray has.
+// Padding entries (pixels past n_pixels, pixels that take no more samples) get a zero direction, which no camera ray
+// has.
 __global__ __launch_bounds__(BLOCK) void raygen_kernel(RenderArgs a) {
     const uint32_t seg = blockIdx.x % (uint32_t)SEGMENTS;
     const uint32_t i = (blockIdx.x / (uint32_t)SEGMENTS) * (uint32_t)BLOCK + threadIdx.x;
@@ -559,6 +560,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *
     const size_t N = a.n_pixels;
     const float *__restrict__ S = a.state;
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (size_t)gridDim.x * BLOCK) {
+        if (a.pixel_done != nullptr && a.pixel_done[i] != 0u) continue; // stopped in an earlier pass of this call
         float acc[ACCUM_PLANES];
 #pragma unroll
         for (int k = 0; k < ACCUM_PLANES; ++k) acc[k] = accum[(size_t)k * N + i];
@@ -582,8 +584,13 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *
             // crates/rt-cli/src/executor.rs:244-249: the pixel is done for this batch once all channels are precise
             if (a.allowed_error > 0.0f && channel_precise(acc[21], acc[0], acc[3], a.allowed_error) &&
                 channel_precise(acc[21], acc[1], acc[4], a.allowed_error) &&
-                channel_precise(acc[21], acc[2], acc[5], a.allowed_error))
+                channel_precise(acc[21], acc[2], acc[5], a.allowed_error)) {
+                if (a.pixel_done != nullptr) {
+                    a.pixel_done[i] = 1u;
+                    atomicAdd(&a.pixel_done[N], 1u);
+                }
                 break;
+            }
         }
 #pragma unroll
         for (int k = 0; k < ACCUM_PLANES; ++k) accum[(size_t)k * N + i] = acc[k];

@@ -37,19 +37,105 @@ int fail(int code, const std::string &msg) {
             return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
-// HIP events of one call, destroyed on every way out of it.
-struct EventPool {
-    std::vector<hipEvent_t> all;
-    hipEvent_t get() {
+// Device-time stopwatch of one call: intervals are bracketed by pairs of HIP events on one stream, and collect(),
+// called after the host has synchronised with that stream, adds every finished interval to its total and takes the
+// events back for reuse.  However many intervals a call times, it holds only as many events as are in flight
+// between two synchronisation points.
+struct Stopwatch {
+    struct Interval {
+        hipEvent_t begin, end;
+        float *total;
+        bool closed;
+        int id;
+    };
+    std::vector<hipEvent_t> idle;
+    std::vector<Interval> pending;
+    int next_id = 0;
+    bool failed = false;
+    hipEvent_t take() {
+        if (!idle.empty()) {
+            hipEvent_t e = idle.back();
+            idle.pop_back();
+            return e;
+        }
         hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return nullptr;
-        all.push_back(e);
+        if (hipEventCreate(&e) != hipSuccess) {
+            failed = true;
+            return nullptr;
+        }
         return e;
     }
-    ~EventPool() {
-        for (hipEvent_t e : all) (void)hipEventDestroy(e);
+    // Starts an interval on `stream` whose length is added to *total; returns its id for stop(), -1 on failure.
+    int start(hipStream_t stream, float *total) {
+        Interval iv{take(), take(), total, false, next_id};
+        if (!iv.begin || !iv.end) {
+            if (iv.begin) idle.push_back(iv.begin);
+            if (iv.end) idle.push_back(iv.end);
+            return -1;
+        }
+        (void)hipEventRecord(iv.begin, stream);
+        pending.push_back(iv);
+        return next_id++;
+    }
+    void stop(int id, hipStream_t stream) {
+        for (Interval &iv : pending)
+            if (iv.id == id && !iv.closed) {
+                (void)hipEventRecord(iv.end, stream);
+                iv.closed = true;
+            }
+    }
+    void stop_all(hipStream_t stream) {
+        for (Interval &iv : pending)
+            if (!iv.closed) {
+                (void)hipEventRecord(iv.end, stream);
+                iv.closed = true;
+            }
+    }
+    // Only valid right after a synchronisation with the stream: every closed interval has finished.
+    void collect() {
+        std::vector<Interval> open;
+        for (const Interval &iv : pending) {
+            if (!iv.closed) {
+                open.push_back(iv);
+                continue;
+            }
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, iv.begin, iv.end) == hipSuccess) *iv.total += ms;
+            idle.push_back(iv.begin);
+            idle.push_back(iv.end);
+        }
+        pending.swap(open);
+    }
+    ~Stopwatch() {
+        for (const Interval &iv : pending) {
+            (void)hipEventDestroy(iv.begin);
+            (void)hipEventDestroy(iv.end);
+        }
+        for (hipEvent_t e : idle) (void)hipEventDestroy(e);
     }
 };
+
+// Makes a device current for the duration of one entry point and puts the caller's device back on the way out, so a
+// host that shares the thread with other HIP users (PyTorch, its own kernels) keeps its current device.
+struct DeviceScope {
+    int previous = -1;
+    hipError_t status = hipSuccess;
+    explicit DeviceScope(int ordinal) {
+        if (hipGetDevice(&previous) != hipSuccess) previous = -1;
+        if (previous != ordinal) status = hipSetDevice(ordinal);
+        else previous = -1; // already current: nothing to restore
+    }
+    ~DeviceScope() {
+        if (previous >= 0) (void)hipSetDevice(previous);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
+#define USE_DEVICE(dev)                                                                                  \
+    DeviceScope device_scope_((dev)->ordinal);                                                           \
+    if (device_scope_.status != hipSuccess)                                                              \
+    return fail(RTMI_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(device_scope_.status))
 
 } // namespace
 
@@ -67,7 +153,7 @@ struct rtmi_device {
 // reference releases the stream and the counters.
 static void device_release(rtmi_device *dev) {
     if (dev->refs.fetch_sub(1) != 1) return;
-    (void)hipSetDevice(dev->ordinal);
+    DeviceScope scope(dev->ordinal);
     if (dev->stream) {
         (void)hipStreamSynchronize(dev->stream);
         (void)hipStreamDestroy(dev->stream);
@@ -89,9 +175,30 @@ struct rtmi_scene {
     rtd::F4 *d_prims = nullptr;
     uint32_t *d_geom_material = nullptr;
     rtd::Material *d_materials = nullptr;
-    uint32_t *d_spill = nullptr; // traversal stack overflow for a full resident grid
-    uint32_t grid_blocks = 0;    // resident grid the spill buffer is sized for
+    uint32_t *d_spill = nullptr; // traversal stack overflow for a full resident grid; used on dev->stream only, under
+                                 // dev->lock (renders and rtmi_intersect)
+    size_t spill_bytes = 0;
+    uint32_t grid_blocks = 0;    // resident grid the spill buffers are sized for
     rtd::SceneView view{};
+    // rtmi_intersect_device launches on caller-chosen streams, possibly several at once: each launch takes the next
+    // of a few spill buffers of its own and leaves an event behind; the launch that takes the buffer next waits for
+    // that event on its stream.  Buffers are created on first use and only for trees deeper than the LDS stack.
+    static constexpr int SPILL_SLOTS = 4;
+    struct SpillSlot {
+        uint32_t *d = nullptr;
+        hipEvent_t done = nullptr;
+        bool used = false;
+    };
+    std::mutex query_lock; // guards slots / next_slot
+    SpillSlot slots[SPILL_SLOTS];
+    unsigned next_slot = 0;
+    // staging of rtmi_intersect (host arrays), kept between calls and grown on demand; used under dev->lock
+    size_t stage_cap = 0;      // rays the device pair holds
+    rtmi_ray *d_stage_rays = nullptr;
+    rtmi_hit *d_stage_hits = nullptr;
+    size_t pinned_cap = 0;     // rays the pinned host pair holds (small batches only)
+    rtmi_ray *h_stage_rays = nullptr;
+    rtmi_hit *h_stage_hits = nullptr;
 };
 
 struct rtmi_film {
@@ -108,14 +215,10 @@ struct rtmi_film {
     size_t cap_counters = 0;
     uint32_t *d_counts = nullptr; // counts + work, cap_counters entries each
     float *d_resolve = nullptr;
+    uint32_t *d_done = nullptr; // n_pixels flags + 1 count, see rtmi_render
 };
 
 namespace {
-
-int use_device(rtmi_device *dev) {
-    HIP_TRY(hipSetDevice(dev->ordinal));
-    return RTMI_OK;
-}
 
 void free_scene_device(rtmi_scene *s) {
     if (s->d_nodes) (void)hipFree(s->d_nodes);
@@ -124,6 +227,18 @@ void free_scene_device(rtmi_scene *s) {
     if (s->d_materials) (void)hipFree(s->d_materials);
     if (s->d_spill) (void)hipFree(s->d_spill);
     s->d_spill = nullptr;
+    for (auto &slot : s->slots) {
+        if (slot.d) (void)hipFree(slot.d);
+        if (slot.done) (void)hipEventDestroy(slot.done);
+        slot = rtmi_scene::SpillSlot{};
+    }
+    if (s->d_stage_rays) (void)hipFree(s->d_stage_rays);
+    if (s->d_stage_hits) (void)hipFree(s->d_stage_hits);
+    if (s->h_stage_rays) (void)hipHostFree(s->h_stage_rays);
+    if (s->h_stage_hits) (void)hipHostFree(s->h_stage_hits);
+    s->d_stage_rays = s->h_stage_rays = nullptr;
+    s->d_stage_hits = s->h_stage_hits = nullptr;
+    s->stage_cap = s->pinned_cap = 0;
     s->d_nodes = s->d_prims = nullptr;
     s->d_geom_material = nullptr;
     s->d_materials = nullptr;
@@ -175,7 +290,7 @@ void rtmi_device_destroy(rtmi_device *dev) {
 int rtmi_device_count_visits(rtmi_device *dev, int enable) {
     if (!dev) return fail(RTMI_ERR_ARG, "device is NULL");
     std::lock_guard<std::mutex> g(dev->lock);
-    if (int rc = use_device(dev)) return rc;
+    USE_DEVICE(dev);
     dev->count_visits = enable != 0;
     HIP_TRY(hipMemsetAsync(dev->d_visits, 0, 16, dev->stream));
     HIP_TRY(hipStreamSynchronize(dev->stream));
@@ -185,7 +300,7 @@ int rtmi_device_count_visits(rtmi_device *dev, int enable) {
 int rtmi_device_get_visits(rtmi_device *dev, uint64_t out[2]) {
     if (!dev || !out) return fail(RTMI_ERR_ARG, "NULL argument");
     std::lock_guard<std::mutex> g(dev->lock);
-    if (int rc = use_device(dev)) return rc;
+    USE_DEVICE(dev);
     HIP_TRY(hipStreamSynchronize(dev->stream));
     HIP_TRY(hipMemcpy(out, dev->d_visits, 16, hipMemcpyDeviceToHost));
     return RTMI_OK;
@@ -207,10 +322,12 @@ int rtmi_scene_create(rtmi_device *dev, rtmi_scene **out) {
 
 void rtmi_scene_destroy(rtmi_scene *scene) {
     if (!scene) return;
-    (void)hipSetDevice(scene->dev->ordinal);
-    (void)hipStreamSynchronize(scene->dev->stream);
-    free_scene_device(scene);
     rtmi_device *dev = scene->dev;
+    {
+        DeviceScope scope(dev->ordinal);
+        (void)hipStreamSynchronize(dev->stream);
+        free_scene_device(scene);
+    }
     delete scene;
     device_release(dev);
 }
@@ -325,7 +442,7 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
     if (scene->committed) return fail(RTMI_ERR_STATE, "scene already committed");
     rtmi_device *dev = scene->dev;
     std::lock_guard<std::mutex> g(dev->lock);
-    if (int rc = use_device(dev)) return rc;
+    USE_DEVICE(dev);
     const auto t0 = std::chrono::steady_clock::now();
     const size_t n = scene->prims.size();
     rtb::WideBvh bvh;
@@ -361,8 +478,8 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
     {
         scene->grid_blocks = (uint32_t)dev->n_cu * (uint32_t)rtk::extend_blocks_per_cu();
         const size_t deep = bvh.stack_need > (uint32_t)rtk::LDS_STACK ? bvh.stack_need - rtk::LDS_STACK : 0;
-        const size_t spill_bytes = std::max<size_t>(16, deep * scene->grid_blocks * rtk::BLOCK * sizeof(uint32_t));
-        HIP_TRY(hipMalloc((void **)&scene->d_spill, spill_bytes));
+        scene->spill_bytes = std::max<size_t>(16, deep * scene->grid_blocks * rtk::BLOCK * sizeof(uint32_t));
+        HIP_TRY(hipMalloc((void **)&scene->d_spill, scene->spill_bytes));
     }
     scene->view.nodes = scene->d_nodes;
     scene->view.prims = scene->d_prims;
@@ -413,49 +530,111 @@ int rtmi_scene_geometry_material(const rtmi_scene *scene, uint32_t geom, uint32_
 int rtmi_intersect_device(rtmi_scene *scene, const rtmi_ray *d_rays, rtmi_hit *d_hits, size_t n, void *hip_stream) {
     if (!scene || (n && (!d_rays || !d_hits))) return fail(RTMI_ERR_ARG, "rtmi_intersect_device: NULL argument");
     if (!scene->committed) return fail(RTMI_ERR_STATE, "scene not committed");
-    if (int rc = use_device(scene->dev)) return rc;
+    if (n == 0) return RTMI_OK;
+    USE_DEVICE(scene->dev);
     static_assert(sizeof(rtmi_ray) == sizeof(rtk::RayAoS) && sizeof(rtmi_hit) == sizeof(rtk::HitAoS), "layout");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (scene->info.stack_need <= (uint32_t)rtk::LDS_STACK) {
+        // the whole stack fits LDS: launches share nothing
+        if (rtk::launch_intersect(scene->view, reinterpret_cast<const rtk::RayAoS *>(d_rays),
+                                  reinterpret_cast<rtk::HitAoS *>(d_hits), n, scene->d_spill, scene->grid_blocks, stream))
+            return fail(RTMI_ERR_DEVICE, "intersect kernel launch failed");
+        return RTMI_OK;
+    }
+    std::lock_guard<std::mutex> g(scene->query_lock);
+    rtmi_scene::SpillSlot &slot = scene->slots[scene->next_slot % rtmi_scene::SPILL_SLOTS];
+    if (!slot.d) {
+        HIP_TRY(hipMalloc((void **)&slot.d, scene->spill_bytes));
+        hipError_t e = hipEventCreateWithFlags(&slot.done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipFree(slot.d);
+            slot.d = nullptr;
+            return fail(RTMI_ERR_DEVICE, std::string("hipEventCreate: ") + hipGetErrorString(e));
+        }
+    }
+    if (slot.used) HIP_TRY(hipStreamWaitEvent(stream, slot.done, 0));
     if (rtk::launch_intersect(scene->view, reinterpret_cast<const rtk::RayAoS *>(d_rays),
-                              reinterpret_cast<rtk::HitAoS *>(d_hits), n, scene->d_spill, scene->grid_blocks, hip_stream))
+                              reinterpret_cast<rtk::HitAoS *>(d_hits), n, slot.d, scene->grid_blocks, stream))
         return fail(RTMI_ERR_DEVICE, "intersect kernel launch failed");
+    HIP_TRY(hipEventRecord(slot.done, stream));
+    slot.used = true;
+    ++scene->next_slot;
     return RTMI_OK;
+}
+
+// Largest |component| a ray origin may have for the culling boxes to stay conservative: boxes are padded by 1e-6 of
+// the scene's largest |coordinate| (scene_build.cpp), which covers the rounding of the slab distances for origins
+// within 16 times that.
+static float origin_limit(const rtmi_scene *scene) {
+    float m = 0.0f;
+    for (int k = 0; k < 3; ++k) m = fmaxf(m, fmaxf(fabsf(scene->lo[k]), fabsf(scene->hi[k])));
+    return 16.0f * m;
 }
 
 int rtmi_intersect(rtmi_scene *scene, const rtmi_ray *rays, rtmi_hit *hits, size_t n) {
     if (!scene || (n && (!rays || !hits))) return fail(RTMI_ERR_ARG, "rtmi_intersect: NULL argument");
     if (!scene->committed) return fail(RTMI_ERR_STATE, "scene not committed");
     if (n == 0) return RTMI_OK;
+    if (!scene->prims.empty()) {
+        const float limit = origin_limit(scene);
+        for (size_t i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k)
+                if (fabsf(rays[i].org[k]) > limit) // NaN passes: such a ray misses everything anyway
+                    return fail(RTMI_ERR_ARG, "rtmi_intersect: ray " + std::to_string(i) + " starts more than 16 scene "
+                                "extents from the origin; move its origin along the ray towards the scene");
+    }
     rtmi_device *dev = scene->dev;
     std::lock_guard<std::mutex> g(dev->lock);
-    if (int rc = use_device(dev)) return rc;
-    rtmi_ray *d_rays = nullptr;
-    rtmi_hit *d_hits = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_rays, n * sizeof(rtmi_ray)));
-    hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(rtmi_hit));
-    if (e != hipSuccess) {
-        (void)hipFree(d_rays);
-        return fail(RTMI_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    USE_DEVICE(dev);
+    // device staging pair, kept between calls
+    if (scene->stage_cap < n) {
+        if (scene->d_stage_rays) (void)hipFree(scene->d_stage_rays);
+        if (scene->d_stage_hits) (void)hipFree(scene->d_stage_hits);
+        scene->d_stage_rays = nullptr;
+        scene->d_stage_hits = nullptr;
+        scene->stage_cap = 0;
+        const size_t cap = std::max<size_t>(n, 1024);
+        HIP_TRY(hipMalloc((void **)&scene->d_stage_rays, cap * sizeof(rtmi_ray)));
+        HIP_TRY(hipMalloc((void **)&scene->d_stage_hits, cap * sizeof(rtmi_hit)));
+        scene->stage_cap = cap;
     }
-    int rc = RTMI_OK;
-    e = hipMemcpyAsync(d_rays, rays, n * sizeof(rtmi_ray), hipMemcpyHostToDevice, dev->stream);
-    if (e == hipSuccess) {
-        rc = rtmi_intersect_device(scene, d_rays, d_hits, n, dev->stream);
-        if (rc == RTMI_OK) e = hipMemcpyAsync(hits, d_hits, n * sizeof(rtmi_hit), hipMemcpyDeviceToHost, dev->stream);
+    // small batches (the per-ray use of Shape::intersection_full) go through pinned host memory: one memcpy each way
+    // instead of the runtime's staging of pageable memory
+    constexpr size_t PINNED_RAYS = 1024;
+    const bool pinned = n <= PINNED_RAYS;
+    if (pinned && scene->pinned_cap == 0) {
+        HIP_TRY(hipHostMalloc((void **)&scene->h_stage_rays, PINNED_RAYS * sizeof(rtmi_ray), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&scene->h_stage_hits, PINNED_RAYS * sizeof(rtmi_hit), hipHostMallocDefault));
+        scene->pinned_cap = PINNED_RAYS;
     }
+    const rtmi_ray *src = rays;
+    rtmi_hit *dst = hits;
+    if (pinned) {
+        memcpy(scene->h_stage_rays, rays, n * sizeof(rtmi_ray));
+        src = scene->h_stage_rays;
+        dst = scene->h_stage_hits;
+    }
+    HIP_TRY(hipMemcpyAsync(scene->d_stage_rays, src, n * sizeof(rtmi_ray), hipMemcpyHostToDevice, dev->stream));
+    // on the library's stream, under the device lock: the render's spill buffer is free
+    if (rtk::launch_intersect(scene->view, reinterpret_cast<const rtk::RayAoS *>(scene->d_stage_rays),
+                              reinterpret_cast<rtk::HitAoS *>(scene->d_stage_hits), n, scene->d_spill, scene->grid_blocks,
+                              dev->stream)) {
+        (void)hipStreamSynchronize(dev->stream);
+        return fail(RTMI_ERR_DEVICE, "intersect kernel launch failed");
+    }
+    hipError_t e = hipMemcpyAsync(dst, scene->d_stage_hits, n * sizeof(rtmi_hit), hipMemcpyDeviceToHost, dev->stream);
     hipError_t e2 = hipStreamSynchronize(dev->stream);
-    (void)hipFree(d_rays);
-    (void)hipFree(d_hits);
-    if (rc != RTMI_OK) return rc;
     if (e != hipSuccess) return fail(RTMI_ERR_DEVICE, std::string("copy: ") + hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(RTMI_ERR_DEVICE, std::string("intersect: ") + hipGetErrorString(e2));
+    if (pinned) memcpy(hits, scene->h_stage_hits, n * sizeof(rtmi_hit));
     return RTMI_OK;
 }
 
 int rtmi_film_create(rtmi_device *dev, const uint32_t *xy, size_t n_pixels, float *d_accum, rtmi_film **out) {
     if (!dev || !out || (n_pixels && !xy)) return fail(RTMI_ERR_ARG, "rtmi_film_create: NULL argument");
-    if (n_pixels >= (1ull << 31)) return fail(RTMI_ERR_LIMIT, "too many pixels in one film");
+    if (n_pixels >= (1ull << 30)) return fail(RTMI_ERR_LIMIT, "2^30 pixels or more in one film");
     std::lock_guard<std::mutex> g(dev->lock);
-    if (int rc = use_device(dev)) return rc;
+    USE_DEVICE(dev);
     rtmi_film *f = new rtmi_film();
     f->dev = dev;
     f->n_pixels = n_pixels;
@@ -487,7 +666,7 @@ int rtmi_film_create(rtmi_device *dev, const uint32_t *xy, size_t n_pixels, floa
 
 void rtmi_film_destroy(rtmi_film *film) {
     if (!film) return;
-    (void)hipSetDevice(film->dev->ordinal);
+    DeviceScope scope(film->dev->ordinal);
     (void)hipStreamSynchronize(film->dev->stream);
     if (film->d_xy) (void)hipFree(film->d_xy);
     if (film->own_accum && film->d_accum) (void)hipFree(film->d_accum);
@@ -497,6 +676,7 @@ void rtmi_film_destroy(rtmi_film *film) {
     if (film->d_queue[1]) (void)hipFree(film->d_queue[1]);
     if (film->d_counts) (void)hipFree(film->d_counts);
     if (film->d_resolve) (void)hipFree(film->d_resolve);
+    if (film->d_done) (void)hipFree(film->d_done);
     rtmi_device *dev = film->dev;
     delete film;
     device_release(dev);
@@ -505,7 +685,7 @@ void rtmi_film_destroy(rtmi_film *film) {
 int rtmi_film_clear(rtmi_film *film) {
     if (!film) return fail(RTMI_ERR_ARG, "film is NULL");
     std::lock_guard<std::mutex> g(film->dev->lock);
-    if (int rc = use_device(film->dev)) return rc;
+    USE_DEVICE(film->dev);
     HIP_TRY(hipMemsetAsync(film->d_accum, 0, film->n_pixels * RTMI_ACCUM_PLANES * sizeof(float), film->dev->stream));
     HIP_TRY(hipStreamSynchronize(film->dev->stream));
     return RTMI_OK;
@@ -516,7 +696,7 @@ float *rtmi_film_accum_device(rtmi_film *film) { return film ? film->d_accum : n
 int rtmi_film_download(rtmi_film *film, float *accum) {
     if (!film || !accum) return fail(RTMI_ERR_ARG, "rtmi_film_download: NULL argument");
     std::lock_guard<std::mutex> g(film->dev->lock);
-    if (int rc = use_device(film->dev)) return rc;
+    USE_DEVICE(film->dev);
     HIP_TRY(hipStreamSynchronize(film->dev->stream));
     HIP_TRY(hipMemcpy(accum, film->d_accum, film->n_pixels * RTMI_ACCUM_PLANES * sizeof(float),
                       hipMemcpyDeviceToHost));
@@ -528,7 +708,7 @@ int rtmi_film_resolve(rtmi_film *film, float *out, int srgb) {
     if (film->n_pixels == 0) return RTMI_OK;
     rtmi_device *dev = film->dev;
     std::lock_guard<std::mutex> g(dev->lock);
-    if (int rc = use_device(dev)) return rc;
+    USE_DEVICE(dev);
     const size_t bytes = film->n_pixels * RTMI_RESOLVE_PLANES * sizeof(float);
     if (!film->d_resolve) HIP_TRY(hipMalloc((void **)&film->d_resolve, bytes));
     if (rtk::launch_resolve(film->d_accum, (uint32_t)film->n_pixels, film->d_resolve, srgb, dev->stream))
@@ -553,16 +733,27 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     const uint32_t n_samples = params->sample_end - params->sample_begin;
     const size_t npix = film->n_pixels;
     if (n_samples == 0 || npix == 0 || params->max_depth == 0) return RTMI_OK; // nothing accumulates
-    if (params->max_depth > (1u << 20)) return fail(RTMI_ERR_LIMIT, "max_depth too large");
+    if (params->max_depth > RTMI_MAX_RAY_DEPTH) return fail(RTMI_ERR_LIMIT, "max_depth above RTMI_MAX_RAY_DEPTH");
 
     rtmi_device *dev = scene->dev;
     std::lock_guard<std::mutex> g(dev->lock);
-    if (int rc = use_device(dev)) return rc;
+    USE_DEVICE(dev);
     hipStream_t stream = dev->stream;
+    const bool adaptive = params->allowed_error > 0.0f;
+
+    // path ids are laid out per 64-pixel block (see kernels.h): pad the pixel count to whole blocks
+    const size_t n_blocks = (npix + rtk::PIXEL_BLOCK - 1) / rtk::PIXEL_BLOCK;
+    const size_t padded_pix = n_blocks * rtk::PIXEL_BLOCK;
+    const size_t seg_blocks = (n_blocks + rtk::SEGMENTS - 1) / rtk::SEGMENTS;
+    const size_t queue_pix = seg_blocks * rtk::SEGMENTS * rtk::PIXEL_BLOCK; // per sample, all segments
+    // a plane of path or queue data is addressed with a 32-bit byte offset: one sample of every pixel must fit
+    if (queue_pix >= (1ull << 30)) return fail(RTMI_ERR_LIMIT, "film has 2^30 pixels or more");
 
     // samples traced together per pass
     // Default: as many samples of every pixel in flight as fit a quarter of the free HBM (164 bytes of state, hit
-    // record and two queue entries per path), so that the long, thin tail of deep bounces is paid once per frame and not once per small pass.
+    // record and two queue entries per path), so that the long, thin tail of deep bounces is paid once per frame and
+    // not once per small pass.  With --allowed-error a pixel that has become precise is not traced in later passes of
+    // the call, so the default is short passes: at most 7 samples per pixel and call are traced without being used.
     uint32_t spp_pass = params->samples_per_pass;
     if (spp_pass == 0) {
         size_t free_b = 0, total_b = 0;
@@ -573,14 +764,9 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         }
         target_paths = std::min<size_t>(target_paths, (size_t)1 << 28);
         spp_pass = (uint32_t)std::max<size_t>(1, target_paths / npix);
+        if (adaptive) spp_pass = std::min(spp_pass, 8u);
     }
     spp_pass = std::min(spp_pass, n_samples);
-    // path ids are laid out per 64-pixel block (see kernels.h): pad the pixel count to whole blocks
-    const size_t n_blocks = (npix + rtk::PIXEL_BLOCK - 1) / rtk::PIXEL_BLOCK;
-    const size_t padded_pix = n_blocks * rtk::PIXEL_BLOCK;
-    const size_t seg_blocks = (n_blocks + rtk::SEGMENTS - 1) / rtk::SEGMENTS;
-    const size_t queue_pix = seg_blocks * rtk::SEGMENTS * rtk::PIXEL_BLOCK; // per sample, all segments
-    // a plane of path or queue data is addressed with a 32-bit byte offset
     if ((size_t)spp_pass * queue_pix >= (1ull << 30))
         spp_pass = (uint32_t)std::max<size_t>(1, ((1ull << 30) - 1) / queue_pix);
     const size_t max_paths = (size_t)spp_pass * queue_pix;
@@ -610,8 +796,17 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         HIP_TRY(hipMalloc((void **)&film->d_counts, 2 * n_counters * sizeof(uint32_t)));
         film->cap_counters = n_counters;
     }
+    // "precise enough, done for this call" flag per pixel + their count: only when a call with --allowed-error spans
+    // several passes (within one pass accumulate_kernel's own sample loop stops the pixel)
+    const bool use_done = adaptive && n_passes > 1;
+    if (use_done) {
+        if (!film->d_done) HIP_TRY(hipMalloc((void **)&film->d_done, (npix + 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(film->d_done, 0, (npix + 1) * sizeof(uint32_t), stream));
+    }
     uint32_t *d_counts = film->d_counts;
     uint32_t *d_work = film->d_counts + film->cap_counters;
+    // only the counters of the bounces this call can reach are zeroed per pass
+    const size_t used_counters = n_counters;
     std::vector<uint32_t> h_counts(per_bounce), h_all;
 
     rtk::RenderArgs a{};
@@ -630,6 +825,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.payload[0] = film->d_queue[0];
     a.payload[1] = film->d_queue[1];
     a.visit_counters = dev->count_visits ? dev->d_visits : nullptr;
+    a.pixel_done = use_done ? film->d_done : nullptr;
     a.n_pixels = (uint32_t)npix;
     a.n_blocks = (uint32_t)n_blocks;
     a.strata = (uint32_t)floorf(sqrtf((float)params->spp)); // executor.rs:218
@@ -639,7 +835,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.integrator = params->integrator;
     a.seed = params->seed;
 
-    a.allowed_error = (params->allowed_error > 0.0f) ? params->allowed_error : 0.0f;
+    a.allowed_error = adaptive ? params->allowed_error : 0.0f;
     a.refill_below = 48;
     a.leaf_bias = 0;
     if (const char *v = getenv("RTMI_REFILL_BELOW")) a.refill_below = atoi(v);
@@ -648,21 +844,27 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.spill = scene->d_spill;
     const uint32_t full_grid = scene->grid_blocks;
 
-    EventPool events;
-    hipEvent_t ev_begin = events.get(), ev_end = events.get();
-    std::vector<hipEvent_t> ev_extend; // pairs
-    std::vector<hipEvent_t> ev_pass(2 * (size_t)n_passes);
-    for (auto &e : ev_pass) e = events.get();
-    if (!ev_begin || !ev_end || std::find(ev_pass.begin(), ev_pass.end(), nullptr) != ev_pass.end())
-        return fail(RTMI_ERR_DEVICE, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(ev_begin, stream));
+    Stopwatch watch;
+    float total_ms = 0.0f, bounce_ms = 0.0f, extend_ms = 0.0f;
+    const int t_total = watch.start(stream, &total_ms);
+    if (t_total < 0) return fail(RTMI_ERR_DEVICE, "hipEventCreate failed");
     int rc = RTMI_OK;
     uint32_t sample = params->sample_begin;
     uint64_t rays = 0, paths = 0, tail_rays_traced = 0;
     uint64_t tail_rays = 1u << 18;
     if (const char *v = getenv("RTMI_TAIL_RAYS")) tail_rays = (uint64_t)atoll(v);
     uint32_t deepest = 0, launches = 0;
+    uint32_t n_done = 0; // pixels already precise enough for this call (use_done only)
     const uint32_t waves_per_block = rtk::BLOCK / 64;
+    // Synchronises with the stream after a small device-to-host copy; every timed interval closed before it is then
+    // finished.
+    auto read_back = [&](void *dst, const void *src, size_t bytes) -> int {
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+        watch.collect();
+        return RTMI_OK;
+    };
     for (uint32_t pass = 0; pass < n_passes && rc == RTMI_OK; ++pass) {
         const uint32_t k = std::min(spp_pass, params->sample_end - sample);
         a.samples = k;
@@ -671,12 +873,13 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         a.sample_base = sample;
         a.counts = d_counts;
         a.work = d_work;
-        hipError_t e = hipMemsetAsync(film->d_counts, 0, 2 * film->cap_counters * sizeof(uint32_t), stream);
+        hipError_t e = hipMemsetAsync(d_counts, 0, used_counters * sizeof(uint32_t), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_work, 0, used_counters * sizeof(uint32_t), stream);
         if (e != hipSuccess) {
             rc = fail(RTMI_ERR_DEVICE, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
             break;
         }
-        (void)hipEventRecord(ev_pass[2 * pass], stream);
+        const int t_pass = watch.start(stream, &bounce_ms);
         if (rtk::launch_raygen(a, stream)) {
             rc = fail(RTMI_ERR_DEVICE, "raygen kernel launch failed");
             break;
@@ -684,10 +887,11 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         // `live` / `longest`: rays entering the bounce about to be launched and the entries of its longest segment,
         // from the survivor counters read back after every bounce.  Once fewer than tail_rays are left a launch per
         // bounce costs more than the bounce, and one tail_kernel launch runs the remaining paths to their end.
-        uint64_t live = (uint64_t)k * npix;
+        uint64_t live = (uint64_t)k * (npix - n_done);
         uint32_t longest = a.seg_cap;
         uint32_t launched = 0, tail_from = 0; // bounces whose counters are valid; first bounce of the tail (0 = none)
         paths += live;
+        const uint64_t camera_rays = live;
         for (uint32_t depth = 0; depth < params->max_depth && live > 0; ++depth) {
             if (depth > 0 && live < tail_rays &&
                 (uint64_t)((longest + rtk::BLOCK - 1) / rtk::BLOCK) * rtk::SEGMENTS <= full_grid) {
@@ -703,15 +907,10 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full_grid, want_blocks));
             const uint64_t per_wave = entries / ((uint64_t)grid * waves_per_block * rtk::SEGMENTS) / 8;
             a.claim = 64u * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, per_wave / 64));
-            // events around the traversal launch only: its time is what the roofline of the dominant kernel needs
-            hipEvent_t ev0 = events.get(), ev1 = events.get();
-            if (ev0 && ev1) {
-                ev_extend.push_back(ev0);
-                ev_extend.push_back(ev1);
-                (void)hipEventRecord(ev0, stream);
-            }
+            // timed on its own: the traversal launch is what the roofline of the dominant kernel needs
+            const int t_extend = watch.start(stream, &extend_ms);
             int lrc = rtk::launch_extend(a, depth, grid, stream);
-            if (ev0 && ev1) (void)hipEventRecord(ev1, stream);
+            watch.stop(t_extend, stream);
             if (lrc || rtk::launch_shade(a, depth, longest, stream)) {
                 rc = fail(RTMI_ERR_DEVICE, "extend or shade kernel launch failed");
                 break;
@@ -720,13 +919,9 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             ++launched;
             if (depth + 1 == params->max_depth) break;
             // the survivors' count sizes (or ends) the next launch
-            e = hipMemcpyAsync(h_counts.data(), d_counts + (size_t)(depth + 1) * per_bounce,
-                               per_bounce * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) {
-                rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+            if ((rc = read_back(h_counts.data(), d_counts + (size_t)(depth + 1) * per_bounce,
+                                per_bounce * sizeof(uint32_t))) != RTMI_OK)
                 break;
-            }
             live = 0;
             longest = 0;
             for (int x = 0; x < rtk::SEGMENTS; ++x) {
@@ -735,20 +930,17 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             }
         }
         if (rc != RTMI_OK) break;
+        watch.stop(t_pass, stream);
         // exact ray count and deepest bounce of the pass from the counters of every bounce that ran (read in chunks
         // of 256 bounces up to the first empty one: live counts never grow from one bounce to the next)
-        rays += (uint64_t)k * npix;
+        rays += camera_rays;
         bool ended = false;
         for (uint32_t d0 = 1; d0 < launched && !ended; d0 += 256) {
             const uint32_t d1 = std::min(launched, d0 + 256);
             h_all.resize((size_t)(d1 - d0) * per_bounce);
-            e = hipMemcpyAsync(h_all.data(), d_counts + (size_t)d0 * per_bounce, h_all.size() * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) {
-                rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+            if ((rc = read_back(h_all.data(), d_counts + (size_t)d0 * per_bounce, h_all.size() * sizeof(uint32_t))) !=
+                RTMI_OK)
                 break;
-            }
             for (uint32_t d = d0; d < d1; ++d) {
                 uint64_t n_d = 0;
                 for (int x = 0; x < rtk::SEGMENTS; ++x)
@@ -763,14 +955,17 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             }
         }
         if (rc != RTMI_OK) break;
-        (void)hipEventRecord(ev_pass[2 * pass + 1], stream);
-        if (rc == RTMI_OK && rtk::launch_accumulate(a, film->d_accum, 1.0f, stream))
+        if (rtk::launch_accumulate(a, film->d_accum, 1.0f, stream)) {
             rc = fail(RTMI_ERR_DEVICE, "accumulate kernel launch failed");
+            break;
+        }
+        if (use_done && pass + 1 < n_passes) rc = read_back(&n_done, film->d_done + npix, sizeof(uint32_t));
         sample += k;
     }
-    (void)hipEventRecord(ev_end, stream);
+    watch.stop_all(stream);
     hipError_t e = hipStreamSynchronize(stream);
     if (rc == RTMI_OK && e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+    if (e == hipSuccess) watch.collect();
     if (rc == RTMI_OK && stats) {
         stats->rays = rays;
         stats->tail_rays = tail_rays_traced;
@@ -778,17 +973,9 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         stats->max_bounces = deepest;
         stats->passes = n_passes;
         stats->bounce_launches = launches;
-        for (uint32_t pass = 0; pass < n_passes; ++pass) {
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ev_pass[2 * pass], ev_pass[2 * pass + 1]) == hipSuccess)
-                stats->bounce_ms += ms;
-        }
-        for (size_t k = 0; k + 1 < ev_extend.size(); k += 2) {
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ev_extend[k], ev_extend[k + 1]) == hipSuccess) stats->extend_ms += ms;
-        }
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) stats->gpu_ms = ms;
+        stats->bounce_ms = bounce_ms;
+        stats->extend_ms = extend_ms;
+        stats->gpu_ms = total_ms;
     }
     return rc;
 }

@@ -8,7 +8,7 @@
 use std::ffi::{c_char, c_int, c_void, CStr};
 
 use rt::{
-    material::{LightDescriptor, MaterialDescriptor, MaterialId},
+    material::{DiffuseBxDF, LightDescriptor, MaterialDescriptor, MaterialId},
     math::{bounds::Bounds, point::Point},
     ray::Ray,
     scene::SceneT,
@@ -91,8 +91,13 @@ impl<'a> HipScene<'a> {
     pub fn new(device: &'a HipDevice) -> Self {
         let mut raw = std::ptr::null_mut();
         must(unsafe { rtmi_scene_create(device.0, &mut raw) }, "rtmi_scene_create");
-        Self { device, raw, materials: Vec::new(), lights: Vec::new() }
+        // rtmi_scene_create has already made material 0 the black "Sky" diffuse; keep the host-side table in step
+        // (embree.rs:41-46), so that `world.materials[id.0]` finds what the C side calls `id`.
+        let sky = MaterialDescriptor { label: Some("Sky".into()), material: Box::new(DiffuseBxDF { albedo: [0.0, 0.0, 0.0].into() }) };
+        Self { device, raw, materials: vec![sky], lights: Vec::new() }
     }
+    /// World { objects, lights, materials, world_material } over this scene (embree.rs:90-97).
+    pub fn sky_material(&self) -> MaterialId { MaterialId(0) }
     pub fn commit(&mut self) -> anyhow::Result<CommittedHipScene<'_, 'a>> {
         let rc = unsafe { rtmi_scene_commit(self.raw, None, std::ptr::null_mut()) };
         if rc != 0 { anyhow::bail!("rtmi_scene_commit: {}", last_error()); }
@@ -117,6 +122,7 @@ impl SceneT for HipScene<'_> {
         let mut id = 0u32;
         must(unsafe { rtmi_scene_insert_material(self.raw, &pod, &mut id) }, "insert_material");
         self.materials.push(mat);
+        debug_assert_eq!(id as usize, self.materials.len() - 1, "host and device material tables out of step");
         MaterialId(id as usize)
     }
     fn insert_light(&mut self, light: LightDescriptor) {
@@ -140,6 +146,13 @@ impl SceneT for HipScene<'_> {
 pub struct CommittedHipScene<'c, 'a> { scene: &'c HipScene<'a> }
 unsafe impl Send for CommittedHipScene<'_, '_> {}
 unsafe impl Sync for CommittedHipScene<'_, '_> {}
+
+impl CommittedHipScene<'_, '_> {
+    /// embree.rs:90-97
+    pub fn into_world(&self) -> anyhow::Result<rt::renderer::World> {
+        Ok(rt::renderer::World { objects: self, lights: &self.scene.lights, materials: &self.scene.materials, world_material: self.scene.sky_material() })
+    }
+}
 
 impl Shape for CommittedHipScene<'_, '_> {
     /// One ray per call keeps the trait working; integrators that stay on the CPU should batch through

@@ -117,9 +117,9 @@ def test_axis_aligned_and_degenerate_rays(oracle, scene_classes, device):
 
 
 def render_both(oracle, so, world, device, width, height, spp, max_depth=64, seed=0, integrator=0, xy=None,
-                sample_range=None, samples_per_pass=0):
+                sample_range=None, samples_per_pass=0, cam=None):
     from raytracing_amd import api, types
-    cam = types.Camera.from_dimensions(width, height)
+    cam = cam or types.Camera.from_dimensions(width, height)
     if xy is None:
         xy = full_frame_xy(width, height)
     rng = sample_range or range(0, spp)
@@ -160,6 +160,35 @@ def test_accumulators_bit_equal_to_oracle(oracle, scene_classes, device, monkeyp
         assert st["tail_rays"] > 0 or st["rays"] == st["paths"]
     eq = same_bits(got, want)
     assert eq.all(), "%d of %d accumulator words differ" % ((~eq).sum(), eq.size)
+
+
+@pytest.mark.parametrize("tail", ["kernels per bounce", "tail kernel", "tail kernel late"])
+@pytest.mark.parametrize("aperture", [0.0, 0.1])
+def test_thin_and_smooth_dielectrics_and_thin_lens_camera(oracle, device, monkeypatch, tail, aperture):
+    """ThinDielectricBxDF, the specular branch and the ior == 1 shortcut of DielectricBxDF (material/mod.rs:249-271,
+    339-366), seen through a rotated, off-axis camera with and without a finite aperture (camera.rs:62-85,
+    quaternion.rs:12-27): accumulators bit-equal to the oracle, and the camera's rays equal the oracle's."""
+    from tests.helpers import OpticsLabScene, lab_camera
+    if tail == "kernels per bounce":
+        monkeypatch.setenv("RTMI_TAIL_RAYS", "0")
+    elif tail == "tail kernel late":
+        monkeypatch.setenv("RTMI_TAIL_RAYS", "3000")
+    so, world = build_pair(oracle, OpticsLabScene, device)
+    W, H, spp = 128, 72, 6
+    cam = lab_camera(W, H, aperture)
+    got, st, want, want_rays = render_both(oracle, so, world, device, W, H, spp, cam=cam, max_depth=24)
+    assert st["rays"] == want_rays and st["rays"] > 2 * W * H * spp
+    eq = same_bits(got, want)
+    assert eq.all(), "%d of %d accumulator words differ" % ((~eq).sum(), eq.size)
+    # every material was reached by a primary ray, and the lens moves the rays when it is open
+    xy = full_frame_xy(W, H)
+    rays = so.camera_rays(cam, oracle.make_params(spp=spp), xy[::7], 1)
+    rays["tnear"] = 1e-5
+    hits = world.intersect(rays)
+    check_hits(hits, so.intersect(rays, oracle.ISECT_BRUTE))
+    assert set(np.unique(hits["mat_id"][hits["geom_id"] != 0xFFFFFFFF])) >= {1, 2, 3, 4, 5}
+    pinhole = so.camera_rays(lab_camera(W, H, 0.0), oracle.make_params(spp=spp), xy[::7], 1)
+    assert (np.abs(rays["dir"] - pinhole["dir"]).max() > 1e-3) == (aperture > 0)
 
 
 def test_passes_do_not_change_the_result(oracle, scene_classes, device):
