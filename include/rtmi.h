@@ -217,6 +217,19 @@ int rtmi_intersect(rtmi_scene *scene, const rtmi_ray *rays, rtmi_hit *hits, size
  * stream for the first to finish. */
 int rtmi_intersect_device(rtmi_scene *scene, const rtmi_ray *d_rays, rtmi_hit *d_hits, size_t n, void *hip_stream);
 
+/* rtmi_intersect_device for callers that cannot allocate device memory while they run (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): no counterpart in the reference.  Same arguments,
+ * results and asynchrony as rtmi_intersect_device, but the traversal's stack-overflow buffer is a fixed 32 MiB array
+ * inside the library's code object (one copy per GPU, held until the process ends) instead of buffers created on first
+ * use, and the call issues no hipMalloc / hipFree, ever.  Limits: trees with rtmi_scene_info.stack_need above
+ * RTMI_STATIC_MAX_STACK are refused with RTMI_ERR_LIMIT, and on deep trees the launch uses fewer waves than
+ * rtmi_intersect_device so that their overflow fits the array.  Every call on one GPU shares that GPU's array:
+ * two of these calls that overlap on one GPU (different streams, or different threads) race on deep trees; keep them
+ * on one stream.  The array needs no clearing between calls (a stack entry is written before it is read). */
+#define RTMI_STATIC_MAX_STACK 152u
+int rtmi_intersect_device_static(rtmi_scene *scene, const rtmi_ray *d_rays, rtmi_hit *d_hits, size_t n,
+                                 void *hip_stream);
+
 /* The per-pixel accumulators the executor keeps (Dispatcher::tiles_data, executor.rs:177-205; RaySeries,
  * crates/rt/src/renderer.rs:24-34) for an explicit list of pixels: xy = n_pixels x (x, y) uint32, host array.
  * Accumulators live on the GPU as RTMI_ACCUM_PLANES planes of n_pixels floats, plane-major:

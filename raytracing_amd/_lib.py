@@ -89,6 +89,7 @@ SIGNATURES = {
     "rtmi_scene_geometry_material": (C.c_int, [_vp, _u32, _u32p]),
     "rtmi_intersect": (C.c_int, [_vp, _vp, _vp, _sz]),
     "rtmi_intersect_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "rtmi_intersect_device_static": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "rtmi_film_create": (C.c_int, [_vp, _vp, _sz, _vp, C.POINTER(_vp)]),
     "rtmi_film_destroy": (None, [_vp]),
     "rtmi_film_clear": (C.c_int, [_vp]),

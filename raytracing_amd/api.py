@@ -226,6 +226,10 @@ class CommittedHipScene:
     def intersect_device(self, d_rays: int, d_hits: int, n: int, stream=None):
         check(self._l.rtmi_intersect_device(self._h, C.c_void_p(d_rays), C.c_void_p(d_hits), n, stream))
 
+    def intersect_device_static(self, d_rays: int, d_hits: int, n: int, stream=None):
+        """intersect_device without any device allocation, ever (rtmi_intersect_device_static)."""
+        check(self._l.rtmi_intersect_device_static(self._h, C.c_void_p(d_rays), C.c_void_p(d_hits), n, stream))
+
 
 @dataclass(frozen=True)
 class Tile:

@@ -81,6 +81,10 @@ struct RenderArgs {
 // d_spill must hold max(0, stack_need - LDS_STACK) * grid_blocks * BLOCK entries (stack_need = the tree's worst case).
 int launch_intersect(const rtd::SceneView &scene, const RayAoS *d_rays, HitAoS *d_hits, size_t n, uint32_t *d_spill,
                      uint32_t grid_blocks, void *stream);
+// Device address and size (in 32-bit words) of the statically allocated stack-overflow buffer on the current device;
+// nonzero on failure.  The address differs from device to device: look it up once per device, with that device
+// current.
+int static_spill_address(uint32_t **out, size_t *words);
 int launch_raygen(const RenderArgs &args, void *stream); // camera rays of a pass, before launch_extend(depth 0)
 int launch_extend(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream);
 // one thread per queue entry; max_segment_entries = the longest segment's entry count at this bounce

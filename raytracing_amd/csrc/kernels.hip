@@ -143,6 +143,22 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const
     }
 }
 
+// Stack-overflow buffer of the batch closest-hit entry point that must not allocate: a file-scope array every GPU
+// holds a copy of from the moment the library is loaded there until the process ends.  Host code must never use the
+// array's name as an address (on the host it is only a stand-in for the symbol): static_spill_address() asks the
+// runtime for the device address, once per device, and every kernel argument goes through that pointer.
+constexpr size_t STATIC_SPILL_WORDS = (size_t)8 << 20; // 32 MiB
+static __device__ __align__(256) uint32_t scratch[STATIC_SPILL_WORDS];
+
+int static_spill_address(uint32_t **out, size_t *words) {
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) return e != hipSuccess ? (int)e : -1;
+    *out = static_cast<uint32_t *>(p);
+    *words = STATIC_SPILL_WORDS;
+    return 0;
+}
+
 // Element idx of a plane: uniform plane base + 32-bit byte offset (a plane is at most 4 GiB).
 __device__ __forceinline__ float ldp(const float *plane, uint32_t idx) {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(plane) + (idx << 2));

@@ -146,6 +146,8 @@ struct rtmi_device {
     bool count_visits = false;
     uint32_t *d_visits = nullptr; // two 64-bit counters
     int n_cu = 256;
+    uint32_t *static_spill = nullptr; // this device's copy of the statically allocated stack-overflow buffer
+    size_t static_spill_words = 0;
     std::atomic<int> refs{1}; // the handle itself + one per scene and film created on it
 };
 
@@ -278,6 +280,13 @@ int rtmi_device_create(int hip_ordinal, rtmi_device **out) {
         return fail(RTMI_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
     (void)hipMemset(d->d_visits, 0, 16);
+    if (int se = rtk::static_spill_address(&d->static_spill, &d->static_spill_words)) {
+        (void)hipFree(d->d_visits);
+        (void)hipStreamDestroy(d->stream);
+        delete d;
+        return fail(RTMI_ERR_DEVICE, "hipGetSymbolAddress(static stack-overflow buffer) failed with code " +
+                                         std::to_string(se));
+    }
     *out = d;
     return RTMI_OK;
 }
@@ -559,6 +568,33 @@ int rtmi_intersect_device(rtmi_scene *scene, const rtmi_ray *d_rays, rtmi_hit *d
     HIP_TRY(hipEventRecord(slot.done, stream));
     slot.used = true;
     ++scene->next_slot;
+    return RTMI_OK;
+}
+
+int rtmi_intersect_device_static(rtmi_scene *scene, const rtmi_ray *d_rays, rtmi_hit *d_hits, size_t n,
+                                 void *hip_stream) {
+    if (!scene || (n && (!d_rays || !d_hits)))
+        return fail(RTMI_ERR_ARG, "rtmi_intersect_device_static: NULL argument");
+    if (!scene->committed) return fail(RTMI_ERR_STATE, "scene not committed");
+    if (n == 0) return RTMI_OK;
+    rtmi_device *dev = scene->dev;
+    USE_DEVICE(dev);
+    // the grid is cut down to what the fixed buffer covers: `deep` overflow entries per launched thread
+    uint32_t grid_cap = scene->grid_blocks;
+    if (scene->info.stack_need > RTMI_STATIC_MAX_STACK)
+        return fail(RTMI_ERR_LIMIT, "rtmi_intersect_device_static: the tree needs " +
+                                        std::to_string(scene->info.stack_need) + " traversal stack entries, more than "
+                                        "RTMI_STATIC_MAX_STACK; use rtmi_intersect_device");
+    if (scene->info.stack_need > (uint32_t)rtk::LDS_STACK) {
+        const size_t deep = scene->info.stack_need - rtk::LDS_STACK;
+        const size_t fit = dev->static_spill_words / (deep * rtk::BLOCK);
+        if (fit == 0) return fail(RTMI_ERR_LIMIT, "rtmi_intersect_device_static: the static buffer is too small");
+        grid_cap = (uint32_t)std::min<size_t>(grid_cap, fit);
+    }
+    if (rtk::launch_intersect(scene->view, reinterpret_cast<const rtk::RayAoS *>(d_rays),
+                              reinterpret_cast<rtk::HitAoS *>(d_hits), n, dev->static_spill, grid_cap,
+                              (hipStream_t)hip_stream))
+        return fail(RTMI_ERR_DEVICE, "intersect kernel launch failed");
     return RTMI_OK;
 }
 
