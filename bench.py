@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--tile-size", type=int, default=32)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--levels", type=int, default=5, help="subdivision levels of the stand-in dragon mesh")
+    ap.add_argument("--standin-extent", type=float, default=None,
+                    help="height of the stand-in mesh in dragon.obj units (default: calibrated to the reference render)")
     ap.add_argument("--samples-per-pass", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -52,12 +54,12 @@ def parse_args():
     return ap.parse_args()
 
 
-def insert_scene(name, scene, levels):
+def insert_scene(name, scene, levels, extent=None):
     from raytracing_amd import scenes
     if name == "dragon":
-        scenes.DragonScene.insert_into(scene, levels=levels)
+        scenes.DragonScene.insert_into(scene, levels=levels, extent=extent)
     elif name == "dragon-diffuse":
-        scenes.DragonScene.insert_into(scene, diffuse=True, levels=levels)
+        scenes.DragonScene.insert_into(scene, diffuse=True, levels=levels, extent=extent)
     else:
         scenes.AVAILABLE_SCENES[name].insert_into(scene)
 
@@ -69,7 +71,7 @@ def cpu_baseline(args, camera, tiler):
     from raytracing_amd import distributed as D
     t0 = time.time()
     so = O.OracleScene()
-    insert_scene(args.scene, so, args.levels)
+    insert_scene(args.scene, so, args.levels, args.standin_extent)
     so.commit()
     build_s = time.time() - t0
     xy = D.tile_pixels(tiler, range(0, tiler.tile_count(), 4))
@@ -123,7 +125,7 @@ def main():
     device = api.Device(local_rank)
     t0 = time.time()
     sg = api.HipScene(device)
-    insert_scene(args.scene, sg, args.levels)
+    insert_scene(args.scene, sg, args.levels, args.standin_extent)
     t_insert = time.time() - t0
     world_scene = sg.commit().into_world()
     info = world_scene.info()

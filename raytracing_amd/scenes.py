@@ -12,7 +12,8 @@ same calls, in the same order, as the reference scene it restates:
 
 `obj/dragon.obj` is not distributed with the reference checkout.  When no such file is found, DragonScene inserts a
 deterministic stand-in of comparable size instead: the Stanford bunny subdivided five times (4968 * 4^5 =
-5,087,232 triangles) with a hashed fractal displacement, scaled to the extent the reference's transform expects.
+5,087,232 triangles) with a hashed fractal displacement, scaled so that it covers the same share of the frame as
+the dragon in the reference's own render of the scene (see standin.py).
 """
 from __future__ import annotations
 
@@ -63,7 +64,7 @@ class DragonScene:
     "multi-bounce diffuse" variant one benchmark configuration names); `levels` sizes the stand-in mesh."""
 
     @staticmethod
-    def insert_into(scene, diffuse=False, levels=5):
+    def insert_into(scene, diffuse=False, levels=5, extent=None):
         if diffuse:
             body = scene.insert_material(MaterialDescriptor(None, DiffuseBxDF(albedo=(0.8, 0.8, 0.8))))
         else:
@@ -79,9 +80,12 @@ class DragonScene:
             scene.dragon_mesh = "obj/dragon.obj"
         else:
             from .standin import dragon_standin
-            positions, indices = dragon_standin(obj_path("standford_bunny.obj"), levels=levels)
+            from .standin import STANDIN_EXTENT
+            extent = STANDIN_EXTENT if extent is None else float(extent)
+            positions, indices = dragon_standin(obj_path("standford_bunny.obj"), levels=levels, extent=extent)
             scene.insert_mesh(body, transform.apply_points(positions), indices)
-            scene.dragon_mesh = "stand-in (subdivided bunny, %d triangles)" % indices.shape[0]
+            scene.dragon_mesh = "stand-in (subdivided bunny, %d triangles, height %g units: the reference dragon's " \
+                                "33.8 %% frame coverage)" % (indices.shape[0], extent)
         scene.insert_light(LightDescriptor(None, (10.2, 80.0, 75.0)))
         ball = scene.insert_material(MaterialDescriptor(None, DiffuseBxDF(albedo=(0.2, 0.1, 0.5))))
         scene.insert_sphere(ball, (-0.7, -0.2, -1.9), 0.8)

@@ -1,0 +1,208 @@
+"""The benchmarked workloads at their full sizes on the GPU, through the C ABI.
+
+At these sizes the oracle cannot render the frame, so each configuration is checked through properties that do not
+need it (determinism, every pixel took exactly spp samples, interleaved tile halves reassemble the frame bit for bit,
+sample ranges merge) plus the oracle, bit for bit, on a strided subset of the pixels, with equal ray counts there.
+
+  Dragon 1920x1080 100 spp     the headline configuration, on the 5,087,232-triangle stand-in mesh (or obj/dragon.obj)
+  Cornell box 1920x1080 5 spp  the reference's own CPU-runnable case (output/gen.sh:6)
+  Dragon 3840x2160 100 spp     more paths than one pass holds: the multi-pass driver at full pixel count
+  Cornell box 3840x2160        at 64 of its 1000 spp (the strata grid stays that of 1000 spp)
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import full_frame_xy, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def frame_order(xy, width):
+    return np.argsort(xy[:, 1].astype(np.int64) * width + xy[:, 0])
+
+
+def render_frame(world, device, cam, spp, tiles=None, sample_range=None, tile_size=32):
+    """All samples of the listed tiles (default: every tile) in the order bench.py lists the pixels."""
+    from raytracing_amd import api
+    from raytracing_amd import distributed as D
+    tiler = api.Tiler(0, 0, cam.width, cam.height, tile_size, tile_size)
+    idx = range(tiler.tile_count()) if tiles is None else tiles
+    xy = D.tile_pixels(tiler, idx, (8, 8))
+    film = api.Film(device, xy)
+    st = api.render(world, film, cam, spp, sample_range)
+    acc = film.download()
+    film.close()
+    return xy, acc, st
+
+
+def check_subset_against_oracle(oracle, so, world, device, cam, spp, xy, acc, stride, sample_range=None):
+    """Every stride-th pixel of the frame: the oracle's accumulators, bit for bit, and -- rendering that subset on its
+    own on the GPU -- the same accumulators again with the oracle's ray count."""
+    from raytracing_amd import api
+    sub = np.arange(stride // 2, xy.shape[0], stride)
+    rng = sample_range or range(0, spp)
+    want, want_rays = so.render(cam, oracle.make_params(spp=spp, sample_begin=rng.start, sample_end=rng.stop), xy[sub])
+    eq = same_bits(acc[:, sub], want)
+    assert eq.all(), "%d of %d accumulator words differ from the oracle" % ((~eq).sum(), eq.size)
+    film = api.Film(device, xy[sub])
+    st = api.render(world, film, cam, spp, rng)
+    got = film.download()
+    film.close()
+    assert st["rays"] == want_rays
+    assert same_bits(got, want).all()
+
+
+@pytest.fixture(scope="module")
+def dragon(oracle, scene_classes, device):
+    from raytracing_amd import api
+    sg = api.HipScene(device)
+    scene_classes["dragon"].insert_into(sg)
+    world = sg.commit().into_world()
+    so = oracle.OracleScene()
+    scene_classes["dragon"].insert_into(so)
+    so.commit()
+    info = world.info()
+    assert info["n_prims"] > 5_000_000 and info["stack_need"] > 24
+    yield so, world
+    sg.close()
+
+
+@pytest.fixture(scope="module")
+def cornell(oracle, scene_classes, device):
+    from raytracing_amd import api
+    sg = api.HipScene(device)
+    scene_classes["cornell-box"].insert_into(sg)
+    world = sg.commit().into_world()
+    so = oracle.OracleScene()
+    scene_classes["cornell-box"].insert_into(so)
+    so.commit()
+    yield so, world
+    sg.close()
+
+
+def test_dragon_1080p_100spp(oracle, dragon, device):
+    from raytracing_amd import types
+    so, world = dragon
+    W, H, spp = 1920, 1080, 100
+    cam = types.Camera.from_dimensions(W, H)
+    xy, whole, st = render_frame(world, device, cam, spp)
+    assert st["paths"] == W * H * spp and st["passes"] == 1 and st["max_bounces"] >= 40
+    assert st["rays"] > 2 * st["paths"]
+    assert (whole[21] == spp).all() and (whole[9] == spp).all()
+    # determinism
+    _, again, st2 = render_frame(world, device, cam, spp)
+    assert st2["rays"] == st["rays"] and same_bits(again, whole).all()
+    del again
+    # interleaved tile halves (what two ranks would render) reassemble the frame
+    n_tiles = 60 * 34
+    parts = [render_frame(world, device, cam, spp, tiles=range(r, n_tiles, 2)) for r in range(2)]
+    assert parts[0][2]["rays"] + parts[1][2]["rays"] == st["rays"]
+    pxy = np.concatenate([p[0] for p in parts], 0)
+    pacc = np.concatenate([p[1] for p in parts], 1)
+    assert same_bits(pacc[:, frame_order(pxy, W)], whole[:, frame_order(xy, W)]).all()
+    del parts, pxy, pacc
+    check_subset_against_oracle(oracle, so, world, device, cam, spp, xy, whole, 4001)
+
+
+def test_dragon_closest_hits(oracle, dragon, device):
+    """200,000 rays against the 5 M-triangle tree (camera rays of a jittered sample, rays between random points of the
+    scene's box, rays leaving the surface as bounce rays do): bit-equal to the oracle's tree, and to brute force on a
+    strided subset."""
+    from raytracing_amd import types
+    so, world = dragon
+    rng = np.random.default_rng(17)
+    W, H = 1920, 1080
+    cam = types.Camera.from_dimensions(W, H)
+    xy = full_frame_xy(W, H)[::31][:66000]
+    cam_rays = so.camera_rays(cam, oracle.make_params(spp=100), xy, 3)
+    lo, hi = world.bounding_box()
+    lo, hi = np.maximum(lo, -1.5), np.minimum(hi, 1.5)
+    n = 67000
+    a = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    b = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    inner = np.zeros(n, dtype=oracle.RAY_DTYPE)
+    inner["org"] = a
+    d = b - a
+    inner["dir"] = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]
+    rays = np.concatenate([cam_rays, inner])
+    rays["tnear"] = 1e-5
+    rays["tfar"] = np.inf
+    first = so.intersect(rays, oracle.ISECT_BVH)
+    hit = first["geom_id"] != 0xFFFFFFFF
+    # second generation: from the hit points, un-offset, into a random direction (pathtracing.rs:58)
+    m = min(int(hit.sum()), 67000)
+    bounce = np.zeros(m, dtype=oracle.RAY_DTYPE)
+    bounce["org"] = first["pos"][hit][:m]
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    bounce["dir"] = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]
+    bounce["tnear"] = 1e-5
+    bounce["tfar"] = np.inf
+    bounce["tfar"][::4] = 0.05
+    rays = np.concatenate([rays, bounce])
+    assert rays.shape[0] >= 190000
+    want = so.intersect(rays, oracle.ISECT_BVH)
+    got = world.intersect(rays)
+    assert got.tobytes() == want.tobytes()
+    assert 0.2 < (want["geom_id"] == 0).mean() < 0.9
+    sub = slice(0, None, 1999)
+    assert got[sub].tobytes() == so.intersect(rays[sub], oracle.ISECT_BRUTE).tobytes()
+
+
+def test_cornell_1080p_5spp(oracle, cornell, device):
+    from raytracing_amd import types
+    so, world = cornell
+    W, H, spp = 1920, 1080, 5
+    cam = types.Camera.from_dimensions(W, H)
+    xy, whole, st = render_frame(world, device, cam, spp)
+    assert st["paths"] == W * H * spp and st["passes"] == 1 and st["max_bounces"] >= 60
+    assert (whole[21] == spp).all()
+    _, again, st2 = render_frame(world, device, cam, spp)
+    assert st2["rays"] == st["rays"] and same_bits(again, whole).all()
+    n_tiles = 60 * 34
+    parts = [render_frame(world, device, cam, spp, tiles=range(r, n_tiles, 2)) for r in range(2)]
+    assert parts[0][2]["rays"] + parts[1][2]["rays"] == st["rays"]
+    pxy = np.concatenate([p[0] for p in parts], 0)
+    pacc = np.concatenate([p[1] for p in parts], 1)
+    assert same_bits(pacc[:, frame_order(pxy, W)], whole[:, frame_order(xy, W)]).all()
+    check_subset_against_oracle(oracle, so, world, device, cam, spp, xy, whole, 499)
+
+
+def test_dragon_4k_100spp_in_several_passes(oracle, dragon, device):
+    """829 M camera paths: more than the library keeps in flight, so the frame takes several passes at 8.3 M pixels."""
+    from raytracing_amd import types
+    so, world = dragon
+    W, H, spp = 3840, 2160, 100
+    cam = types.Camera.from_dimensions(W, H)
+    xy, whole, st = render_frame(world, device, cam, spp)
+    assert st["paths"] == W * H * spp and st["passes"] >= 2
+    assert (whole[21] == spp).all() and (whole[9] == spp).all()
+    check_subset_against_oracle(oracle, so, world, device, cam, spp, xy, whole, 16001)
+    # the same frame as two sample ranges (RaySeries::merge, renderer.rs:84-95): 0..37 then 37..100
+    from raytracing_amd import api
+    film = api.Film(device, xy)
+    a = api.render(world, film, cam, spp, range(0, 37))
+    b = api.render(world, film, cam, spp, range(37, 100))
+    assert a["rays"] + b["rays"] == st["rays"]
+    assert same_bits(film.download(), whole).all()
+    film.close()
+
+
+def test_cornell_4k_strata_of_1000spp(oracle, cornell, device):
+    """Cornell box 3840x2160 on the 31 x 31 strata grid of the 1000-spp configuration, samples 0..64 (the full 1000
+    take 7 s; every sample is independent of how many follow)."""
+    from raytracing_amd import types
+    so, world = cornell
+    W, H, spp = 3840, 2160, 1000
+    cam = types.Camera.from_dimensions(W, H)
+    xy, whole, st = render_frame(world, device, cam, spp, sample_range=range(0, 64))
+    assert st["paths"] == W * H * 64 and (whole[21] == 64).all()
+    assert st["rays"] > 8 * st["paths"]
+    check_subset_against_oracle(oracle, so, world, device, cam, spp, xy, whole, 16001, sample_range=range(0, 64))
+    # samples 990..1000, the wrapped strata (1000 = 31 * 31 + 39): a different range gives different, valid samples
+    sub = np.arange(0, xy.shape[0], 8009)
+    from raytracing_amd import api
+    film = api.Film(device, xy[sub])
+    api.render(world, film, cam, spp, range(990, 1000))
+    want, _ = so.render(cam, oracle.make_params(spp=spp, sample_begin=990, sample_end=1000), xy[sub])
+    assert same_bits(film.download(), want).all()
+    film.close()
