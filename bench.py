@@ -4,16 +4,24 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step is one whole frame: every rank (one process per GPU) traces all samples of its interleaved share of the 32x32
-tiles into accumulators resident in HBM, then the accumulator planes are gathered to rank 0 (RCCL).  The scene
-(mesh, BVH) is built and uploaded before the timed region.  Rank 0 prints one JSON line.
+Run plainly with --gpus N > 1 it starts the N ranks itself (the second command line, as a child process) and passes
+their output through.  A step is one whole frame: every rank (one process per GPU) traces all samples of its
+interleaved share of the 32x32 tiles into a film resident in HBM, then the per-pixel accumulators are gathered into
+rank 0's frame (rtmi_film_gather: RCCL send/receive over xGMI; a local scatter for one rank).  The scene (mesh, BVH) is
+built and uploaded before the timed region.  Rank 0 prints one JSON line.  torch.distributed is used for the launch
+contract only: rendezvous, barriers, the max / sum of the timers, handing out the communicator id.
 
 The dragon mesh the reference uses is not distributed with it; unless assets/obj/dragon.obj exists the scene uses the
 deterministic 5,087,232-triangle stand-in of raytracing_amd/standin.py (config.mesh says which).
+
+--dry-cpu --backend gloo rehearses everything around the GPU work on a machine without GPUs (launcher, rendezvous,
+tile partition, gather of synthetic accumulators, timer reduction, the JSON line); it measures nothing.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +40,7 @@ RAY_BYTES = 24 + 20
 HBM_PEAK_GBS = 8000.0
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -51,7 +59,24 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-visits", action="store_true", help="skip the counting render that sizes the roofline")
-    return ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: --dry-cpu)")
+    ap.add_argument("--dry-cpu", action="store_true", help="rehearse launch, partition and gather without a GPU")
+    ap.add_argument("--gather", default="abi", choices=["abi", "torch"],
+                    help="frame gather: the C ABI's (rtmi_film_gather) or torch.distributed on a torch-owned buffer")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """--gpus N > 1 outside a torch.distributed launch: start the N ranks as a child (never re-exec a process, and
+    nothing here has touched a GPU), pass their output through, leave with their exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def insert_scene(name, scene, levels, extent=None):
@@ -99,25 +124,80 @@ def cpu_baseline(args, camera, tiler):
     }
 
 
+def dry_cpu(args, rank, world):
+    """No GPU: the ranks partition the tiles, fill accumulators with a function of the pixel and the plane, gather them
+    over gloo and reduce their timers, exactly as the measured path does around its GPU work."""
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import api
+    from raytracing_amd import distributed as D
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend)
+    W, H = args.width, args.height
+    tiler = api.Tiler(0, 0, W, H, args.tile_size, args.tile_size)
+    my_tiles = api.tile_partition(tiler.tile_count(), world, rank)
+    xy = D.tile_pixels(tiler, my_tiles, (8, 8))
+    lin = torch.from_numpy(xy[:, 1].astype(np.int64) * W + xy[:, 0].astype(np.int64))
+    planes = torch.arange(api.ACCUM_PLANES, dtype=torch.float32)[:, None]
+    accum = planes * 1e6 + lin[None, :].to(torch.float32)
+    gatherer = D.FrameGatherer(xy, W, H, "cpu")
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps, 1)):
+        frame = gatherer.gather(accum)
+    if world > 1:
+        dist.barrier()
+    t_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    t_cnt = torch.tensor([xy.shape[0], len(my_tiles)], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_cnt, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        want = planes * 1e6 + torch.arange(W * H, dtype=torch.float32)[None, :]
+        ok = bool(torch.equal(frame, want)) and int(t_cnt[0]) == W * H and int(t_cnt[1]) == tiler.tile_count()
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mrays/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t_el.item()) * 1e3,
+                          "dry_cpu": True, "frame_ok": ok, "pixels": int(t_cnt[0]), "tiles": int(t_cnt[1])}))
+        sys.stdout.flush()
+        if not ok:
+            raise SystemExit("dry run: the gathered frame is wrong")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_cpu:
+        return dry_cpu(args, rank, world)
     if "RTMI_BENCH_DEVICE" in os.environ:  # rehearsal of the multi-rank path on a box with fewer GPUs than ranks
         local_rank = int(os.environ["RTMI_BENCH_DEVICE"])
+    # torch first: its wheel carries its own HIP runtime and RCCL, and the library then shares them (see INTEGRATION.md)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only path")
     torch.cuda.set_device(local_rank)
     dev_t = torch.device("cuda", local_rank)
-    if world > 1:
+    # RTMI_BENCH_COMM=1: go through the process group and the RCCL communicator even with one rank (a rehearsal of the
+    # multi-rank code on a one-GPU box: the root then sends its planes to itself through RCCL)
+    use_dist = world > 1 or os.environ.get("RTMI_BENCH_COMM", "0") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev_t)
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        dist.init_process_group(args.backend, device_id=dev_t, rank=rank, world_size=world)
 
     from raytracing_amd import api, types
-    from raytracing_amd import distributed as D
 
     W, H = args.width, args.height
     camera = types.Camera.from_dimensions(W, H)
@@ -133,40 +213,97 @@ def main():
 
     # RTMI_BENCH_SHARE=N: render only the share of tiles one rank of an N-rank job would own (scaling rehearsal on 1 GPU)
     share = int(os.environ.get("RTMI_BENCH_SHARE", "0"))
-    my_tiles = D.partition_tiles(tiler.tile_count(), share, 0) if share > 1 and world == 1 else \
-        D.partition_tiles(tiler.tile_count(), world, rank)
+    my_tiles = api.tile_partition(tiler.tile_count(), share, 0) if share > 1 and world == 1 else \
+        api.tile_partition(tiler.tile_count(), world, rank)
     block = tuple(int(v) for v in os.environ.get("RTMI_BENCH_BLOCK", "8x8").split("x"))
-    xy = D.tile_pixels(tiler, my_tiles, block if block[0] > 0 else None)
-    accum = torch.zeros((api.ACCUM_PLANES, xy.shape[0]), dtype=torch.float32, device=dev_t)
-    torch.cuda.synchronize()
-    film = api.Film(device, xy, accum.data_ptr())
+    film = api.Film.for_tiles(device, tiler, my_tiles, block if block[0] > 0 else None)
+    frame = api.Film.frame(device, W, H) if rank == 0 else None
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gatherer = D.FrameGatherer(xy, W, H, dev_t)
-    frame_buf = torch.zeros((api.ACCUM_PLANES, W * H), dtype=torch.float32, device=dev_t) if rank == 0 else None
+    # the frame gather: the library's own (RCCL through the C ABI), or torch.distributed on a copy of the accumulators
+    comm = None
+    gather_kind = "rtmi_film_gather (RCCL send/recv to rank 0)" if use_dist else "rtmi_film_gather (local scatter)"
+    gatherer = frame_t = None
+
+    def use_torch_gather():
+        nonlocal gatherer, frame_t
+        import ctypes
+        from raytracing_amd import distributed as D
+        accum_t = torch.zeros((api.ACCUM_PLANES, film.n_pixels), dtype=torch.float32, device=dev_t)
+        frame_t = torch.zeros((api.ACCUM_PLANES, W * H), dtype=torch.float32, device=dev_t) if rank == 0 else None
+        gatherer = D.FrameGatherer(film.xy, W, H, dev_t)
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+        def gather():
+            torch.cuda.synchronize()
+            if film.n_pixels:
+                rc = hip.hipMemcpy(accum_t.data_ptr(), film.accum_device(), accum_t.numel() * 4, 3)  # device to device
+                if rc != 0:
+                    raise RuntimeError("hipMemcpy failed: %d" % rc)
+            gatherer.gather(accum_t, frame_t)
+            torch.cuda.synchronize()
+        return gather
+
+    if args.gather == "torch":
+        gather_kind = "torch.distributed gather"
+        gather = use_torch_gather()
+    else:
+        failure = ""
+        try:
+            if use_dist:
+                ident = torch.zeros(api.COMM_ID_BYTES, dtype=torch.uint8, device=dev_t)
+                if rank == 0:
+                    ident.copy_(torch.frombuffer(bytearray(api.Comm.unique_id()), dtype=torch.uint8))
+                dist.broadcast(ident, src=0)
+                comm = api.Comm(device, ident.cpu().numpy().tobytes(), rank, world)
+            film.gather(comm, frame)  # builds the exchange plan (pixel lists to rank 0) outside the timed region
+        except Exception as exc:  # noqa: BLE001 - reported below, on every rank
+            failure = "%s: %s" % (type(exc).__name__, exc)
+        failed = torch.tensor([1 if failure else 0], dtype=torch.int32, device=dev_t)
+        if use_dist:
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()):
+            # said loudly, and in the JSON line: the numbers below then include torch's gather, not the library's
+            sys.stderr.write("[bench rank %d] rtmi_film_gather unusable (%s); using torch.distributed for the gather\n"
+                             % (rank, failure or "another rank failed"))
+            gather_kind = "torch.distributed gather (rtmi_film_gather failed: %s)" % (failure or "on another rank")
+            gather = use_torch_gather()
+        else:
+            def gather():
+                film.gather(comm, frame)
 
     def step():
-        accum.zero_()
-        torch.cuda.synchronize()
+        film.clear()
         st = api.render(world_scene, film, camera, args.spp, None, args.max_ray_depth, 0, args.seed,
                         args.samples_per_pass)
-        frame = gatherer.gather(accum, frame_buf)
-        return st, frame
+        gather()
+        return st
 
-    for _ in range(args.warmup):
+    n_warm = max(args.warmup, 1) if world > 1 else args.warmup
+    for _ in range(n_warm):
         step()
+    if rank == 0 and n_warm > 0:
+        # untimed check of the exchange on the warm-up frame: every pixel of the frame arrived with all its samples
+        acc = frame.download() if gatherer is None else frame_t.cpu().numpy()
+        complete = int((acc[21] == float(args.spp)).sum())
+        expect = W * H if share <= 1 or world > 1 else film.n_pixels
+        if complete != expect:
+            raise SystemExit("bench: the gathered frame is incomplete (%d of %d pixels carry %d samples)" %
+                             (complete, expect, args.spp))
+        del acc
     barrier()
     t0 = time.perf_counter()
     rays = paths = 0
     gpu_ms = bounce_ms = extend_ms = 0.0
     passes = launches = 0
     for _ in range(args.steps):
-        st, frame = step()
+        st = step()
         rays += st["rays"]
         paths += st["paths"]
         gpu_ms += st["gpu_ms"]
@@ -178,7 +315,7 @@ def main():
     elapsed = time.perf_counter() - t0
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
     t_cnt = torch.tensor([rays, paths], dtype=torch.int64, device=dev_t)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(t_cnt, op=dist.ReduceOp.SUM)
     elapsed = float(t_el.item())
@@ -194,7 +331,7 @@ def main():
         roofline = None
         if not args.no_visits:
             device.count_visits(True)
-            film_c = api.Film(device, xy)
+            film_c = api.Film(device, film.xy)
             st_c = api.render(world_scene, film_c, camera, args.spp, None, args.max_ray_depth, 0, args.seed,
                               args.samples_per_pass)
             nodes, records = device.visits()
@@ -212,7 +349,7 @@ def main():
                 try:
                     tj = json.load(open(tfile))
                     key = "%s_%dx%d_%dspp" % (args.scene, W, H, args.spp)
-                    if key in tj:
+                    if key in tj and world == 1 and share <= 1 and args.standin_extent is None:
                         traffic = tj[key]["hbm_bytes_per_launch"]
                 except Exception:
                     traffic = None
@@ -227,6 +364,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "kernel": "extend_kernel",
+                "limited_by": "VALU issue at partial lane utilisation and gather latency (SQ counters in profiles/); "
+                              "priced against HBM peak because its algorithmic work is bytes gathered, not flops",
                 "launches_per_step": n_launch,
                 "avg_launch_ms": extend_ms / max(launches, 1),
                 "kernel_ms_per_step": extend_ms / steps,
@@ -267,6 +406,7 @@ def main():
                 "triangles": int(info["n_prims"]),
                 "bvh_nodes": int(info["n_nodes"]),
                 "partition": "tiles interleaved over %d rank(s), full scene replica per GPU, gather to rank 0" % world,
+                "gather": gather_kind,
             },
             "ms_per_frame": ms_per_step,
             "mpaths_per_s": total_paths / elapsed / 1e6,
@@ -278,8 +418,13 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+        sys.stdout.flush()
     film.close()
-    if world > 1:
+    if frame is not None:
+        frame.close()
+    if comm is not None:
+        comm.close()
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

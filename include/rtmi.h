@@ -152,6 +152,7 @@ typedef struct rtmi_scene_info {
 typedef struct rtmi_device rtmi_device;
 typedef struct rtmi_scene rtmi_scene;
 typedef struct rtmi_film rtmi_film;
+typedef struct rtmi_comm rtmi_comm;
 
 const char *rtmi_last_error(void);
 const char *rtmi_version(void);
@@ -251,6 +252,23 @@ int rtmi_film_download(rtmi_film *film, float *accum);
  * applies OutputBuffers::convert (crates/rt-cli/src/output/mod.rs:46-58): sRGB OETF on the four RGB channels. */
 int rtmi_film_resolve(rtmi_film *film, float *out, int srgb);
 
+/* A film over the interleaved share of a frame's tiles one rank of a multi-GPU job renders: tiles first_tile,
+ * first_tile + tile_stride, ... of the Tiler (offset, width, height, grain; tile.rs:56-97), tile after tile.  With
+ * block_w, block_h > 0 the pixels of a tile are listed block after block of block_w x block_h pixels (row-major
+ * inside a block and between blocks) instead of row by row: the renderer traces 64 consecutive pixels of the list per
+ * wave, and a compact 8 x 8 block of camera rays stays together in the tree longer than a 32 x 2 strip.  The order
+ * never changes a pixel's result. */
+int rtmi_film_create_tiles(rtmi_device *dev, uint32_t offset_x, uint32_t offset_y, uint32_t width, uint32_t height,
+                           uint32_t grain, uint32_t first_tile, uint32_t tile_stride, uint32_t block_w, uint32_t block_h,
+                           rtmi_film **out);
+/* A film over every pixel of the window (offset, width, height), row-major: what OutputBuffers holds for the whole
+ * image (crates/rt-cli/src/output/mod.rs:13-21) and the destination of rtmi_film_gather. */
+int rtmi_film_create_frame(rtmi_device *dev, uint32_t offset_x, uint32_t offset_y, uint32_t width, uint32_t height,
+                           rtmi_film **out);
+size_t rtmi_film_pixel_count(const rtmi_film *film);
+/* The film's pixel list: n_pixels x (x, y) uint32 into a host array. */
+int rtmi_film_pixels(rtmi_film *film, uint32_t *xy);
+
 /* Executor::run_* + tile_worker + pixel_worker (executor.rs:77-270) for the film's pixels: traces samples
  * [sample_begin, sample_end) of every pixel through the wavefront pipeline (camera ray, then per bounce: closest
  * hit, shade, compact) and adds them to the film (RaySeries::add_sample, renderer.rs:63-82).  Synchronous.
@@ -262,6 +280,36 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
 uint32_t rtmi_tile_count(uint32_t width, uint32_t height, uint32_t grain);
 int rtmi_tile_get(uint32_t offset_x, uint32_t offset_y, uint32_t width, uint32_t height, uint32_t grain,
                   uint32_t idx, uint32_t out[4]);
+
+/* ---- several GPUs.  The reference shares one frame between the threads of one process (dispatch_async,
+ * executor.rs:307-330); its unit of work sharing is the 32x32 tile (tile.rs:56-97).  Here every GPU (one rank each: a
+ * process or a thread with its own rtmi_device) holds the whole scene, renders all samples of every world-th tile
+ * into a film of its own (rtmi_film_create_tiles) and the per-pixel accumulators are then gathered into the root's
+ * frame.  Samples depend only on (seed, x, y, sample), so the gathered frame is bit-identical to a one-GPU render. */
+
+/* Rank `rank` of `world` owns tiles *out_first, *out_first + *out_stride, ...: *out_count of the n_tiles.  Interleaved,
+ * because cost per tile varies by an order of magnitude with what the tile sees. */
+int rtmi_tile_partition(uint32_t n_tiles, uint32_t world, uint32_t rank, uint32_t *out_first, uint32_t *out_stride,
+                        uint32_t *out_count);
+
+/* A communicator over RCCL (xGMI between the GPUs of a node).  One rank calls rtmi_comm_unique_id and hands the id to
+ * the others by any means (a file, a socket, MPI, torch.distributed); then every rank calls rtmi_comm_create with it,
+ * all at the same time (the call returns when all `world` ranks have joined).  RCCL is loaded when first needed; a
+ * host without it gets RTMI_ERR_DEVICE here and can still use everything else. */
+#define RTMI_COMM_ID_BYTES 128
+int rtmi_comm_unique_id(unsigned char id[RTMI_COMM_ID_BYTES]);
+int rtmi_comm_create(rtmi_device *dev, const unsigned char id[RTMI_COMM_ID_BYTES], int rank, int world,
+                     rtmi_comm **out);
+void rtmi_comm_destroy(rtmi_comm *comm);
+
+/* The exchange step of a frame: copies every rank's film accumulators (RaySeries of its pixels) into `frame` on rank
+ * `root`, at the pixels' positions there.  Collective: every rank of `comm` calls it with its own film; `frame` is
+ * used on the root only (a film made by rtmi_film_create_frame on the root's device; NULL elsewhere) and pixels no
+ * rank sent keep their old values.  Nothing is reduced: ranks must own disjoint pixels.  comm == NULL is the
+ * single-GPU case (film and frame on one device).  The first call for a (film, comm, root, frame) combination also
+ * exchanges the pixel lists; later calls move only the 88 bytes per pixel, each peer straight to the root.
+ * Synchronous: returns when the frame is complete on the root. */
+int rtmi_film_gather(rtmi_film *film, rtmi_comm *comm, int root, rtmi_film *frame);
 
 #ifdef __cplusplus
 }

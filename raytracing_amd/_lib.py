@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTMI_LIB") or os.path.join(_HERE, "librtmi.so")  # RTMI_LIB: an alternative build of the same library
 
 ACCUM_PLANES = 22
+COMM_ID_BYTES = 128
 RESOLVE_PLANES = 15
 INVALID_ID = 0xFFFFFFFF
 
@@ -91,6 +92,15 @@ SIGNATURES = {
     "rtmi_intersect_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "rtmi_intersect_device_static": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "rtmi_film_create": (C.c_int, [_vp, _vp, _sz, _vp, C.POINTER(_vp)]),
+    "rtmi_film_create_tiles": (C.c_int, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "rtmi_film_create_frame": (C.c_int, [_vp, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "rtmi_film_pixel_count": (_sz, [_vp]),
+    "rtmi_film_pixels": (C.c_int, [_vp, _vp]),
+    "rtmi_film_gather": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "rtmi_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "rtmi_comm_create": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "rtmi_comm_destroy": (None, [_vp]),
+    "rtmi_tile_partition": (C.c_int, [_u32, _u32, _u32, _u32p, _u32p, _u32p]),
     "rtmi_film_destroy": (None, [_vp]),
     "rtmi_film_clear": (C.c_int, [_vp]),
     "rtmi_film_accum_device": (_vp, [_vp]),

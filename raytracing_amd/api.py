@@ -17,7 +17,7 @@ from typing import Callable, Optional
 import numpy as np
 
 from . import _lib
-from ._lib import ACCUM_PLANES, HIT_DTYPE, RAY_DTYPE, RESOLVE_PLANES, RtmiError, check
+from ._lib import ACCUM_PLANES, COMM_ID_BYTES, HIT_DTYPE, RAY_DTYPE, RESOLVE_PLANES, RtmiError, check
 from .types import Camera, RenderRange
 
 MAT_KINDS = {"DiffuseBxDF": 0, "DielectricBxDF": 1, "ThinDielectricBxDF": 2, "EmitBxDF": 3}
@@ -289,6 +289,45 @@ class TileMsg:
     data: np.ndarray  # [len(tile), 15]: Normal, Position, Albedo, Color (3 each), Variance, Z, RayDepth
 
 
+class Comm:
+    """One rank of a multi-GPU job (rtmi_comm): RCCL between the GPUs of a node.  Rank 0 makes the id with
+    Comm.unique_id() and passes it to the other ranks; every rank then constructs its Comm at the same time."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        check(_lib.load().rtmi_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, device: Device, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError("a communicator id has %d bytes" % _lib.COMM_ID_BYTES)
+        self.device, self.rank, self.world = device, int(rank), int(world)
+        self._l = device._l
+        h = C.c_void_p()
+        check(self._l.rtmi_comm_create(device._h, unique_id, self.rank, self.world, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.rtmi_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tile_partition(n_tiles: int, world: int, rank: int) -> range:
+    """rtmi_tile_partition: the tiles rank `rank` of `world` renders (interleaved)."""
+    first, stride, count = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    check(_lib.load().rtmi_tile_partition(int(n_tiles), int(world), int(rank), C.byref(first), C.byref(stride),
+                                          C.byref(count)))
+    return range(first.value, first.value + stride.value * count.value, stride.value)
+
+
 class Film:
     """Per-pixel accumulators on the GPU for an explicit pixel list (Dispatcher::tiles_data, executor.rs:194-201)."""
 
@@ -300,6 +339,43 @@ class Film:
         check(self._l.rtmi_film_create(device._h, self.xy.ctypes.data, self.xy.shape[0],
                                        C.c_void_p(accum_device_ptr) if accum_device_ptr else None, C.byref(h)))
         self._h = h
+
+    @classmethod
+    def _adopt(cls, device: Device, handle):
+        self = cls.__new__(cls)
+        self.device, self._l, self._h = device, device._l, handle
+        n = int(self._l.rtmi_film_pixel_count(handle))
+        self.xy = np.zeros((n, 2), dtype=np.uint32)
+        check(self._l.rtmi_film_pixels(handle, self.xy.ctypes.data))
+        return self
+
+    @classmethod
+    def for_tiles(cls, device: Device, tiler: "Tiler", tiles: range, block=(8, 8)):
+        """rtmi_film_create_tiles: the film of one rank's share of the tiles (`tiles` = first, first + stride, ...)."""
+        if tiler.x_grainsize != tiler.y_grainsize:
+            raise ValueError("square tiles only")
+        tiles = tiles if isinstance(tiles, range) else range(*tiles)
+        if tiles.step <= 0 or (len(tiles) and tiles.stop < tiler.tile_count()):
+            raise ValueError("tiles must be a forward range running to the last tile")
+        bw, bh = block if block else (0, 0)
+        h = C.c_void_p()
+        check(device._l.rtmi_film_create_tiles(device._h, tiler.offset_x, tiler.offset_y, tiler.width, tiler.height,
+                                               tiler.x_grainsize, tiles.start, tiles.step, bw, bh, C.byref(h)))
+        return cls._adopt(device, h)
+
+    @classmethod
+    def frame(cls, device: Device, width: int, height: int, offset=(0, 0)):
+        """rtmi_film_create_frame: every pixel of the window, row-major -- the destination of gather()."""
+        h = C.c_void_p()
+        check(device._l.rtmi_film_create_frame(device._h, int(offset[0]), int(offset[1]), int(width), int(height),
+                                               C.byref(h)))
+        return cls._adopt(device, h)
+
+    def gather(self, comm: Optional["Comm"], frame: Optional["Film"], root: int = 0):
+        """rtmi_film_gather: this rank's accumulators into `frame` on rank `root` (collective over `comm`; comm=None is
+        the single-GPU case)."""
+        check(self._l.rtmi_film_gather(self._h, comm._h if comm is not None else None, int(root),
+                                       frame._h if frame is not None else None))
 
     @property
     def n_pixels(self):

@@ -94,6 +94,12 @@ int launch_shade(const RenderArgs &args, uint32_t depth, uint32_t max_segment_en
 int launch_tail(const RenderArgs &args, uint32_t depth0, uint32_t max_segment_entries, void *stream);
 int extend_blocks_per_cu(); // resident blocks of the traversal kernel per CU (occupancy query)
 int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, void *stream);
+// d_lin[i] = row-major position of pixel d_xy[i] in the window (ox, oy, w, h); *d_bad |= 1 if a pixel lies outside
+int launch_frame_index(const uint32_t *d_xy, uint32_t n, uint32_t ox, uint32_t oy, uint32_t w, uint32_t h,
+                       uint32_t *d_lin, uint32_t *d_bad, void *stream);
+// accumulator planes of n pixels (plane stride n) into the planes of a frame of n_dst pixels at positions d_lin
+int launch_scatter_planes(const float *d_src, uint32_t n, const uint32_t *d_lin, float *d_dst, uint32_t n_dst,
+                          void *stream);
 int launch_resolve(const float *d_accum, uint32_t n_pixels, float *d_out, int srgb, void *stream);
 
 } // namespace rtk

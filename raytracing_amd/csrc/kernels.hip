@@ -654,6 +654,32 @@ __global__ __launch_bounds__(BLOCK) void resolve_kernel(const float *__restrict_
     }
 }
 
+// Position of every listed pixel in a row-major frame window; pixels outside the window raise *bad.
+__global__ __launch_bounds__(BLOCK) void frame_index_kernel(const uint32_t *__restrict__ xy, uint32_t n, uint32_t ox,
+                                                            uint32_t oy, uint32_t w, uint32_t h,
+                                                            uint32_t *__restrict__ lin, uint32_t *bad) {
+    const uint32_t i = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = xy[2 * i] - ox, y = xy[2 * i + 1] - oy; // wraps to a large value when left of / above the window
+    if (x >= w || y >= h) {
+        lin[i] = 0u;
+        atomicOr(bad, 1u);
+    } else {
+        lin[i] = y * w + x;
+    }
+}
+
+// dst[k][lin[i]] = src[k][i] for the ACCUM_PLANES planes of n source pixels (plane strides n and n_dst).
+__global__ __launch_bounds__(BLOCK) void scatter_planes_kernel(const float *__restrict__ src, uint32_t n,
+                                                               const uint32_t *__restrict__ lin,
+                                                               float *__restrict__ dst, uint32_t n_dst) {
+    const uint32_t i = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = lin[i];
+#pragma unroll
+    for (int k = 0; k < ACCUM_PLANES; ++k) dst[(size_t)k * n_dst + j] = src[(size_t)k * n + i];
+}
+
 // ---------------------------------------------------------------------------------------------- launchers
 
 static int check_launch() {
@@ -717,6 +743,22 @@ int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, v
     hipStream_t s = (hipStream_t)stream;
     const uint32_t grid = blocks_for(args.n_pixels, 256u * 16u);
     hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(BLOCK), 0, s, args, d_accum, count_inc);
+    return check_launch();
+}
+
+int launch_frame_index(const uint32_t *d_xy, uint32_t n, uint32_t ox, uint32_t oy, uint32_t w, uint32_t h,
+                       uint32_t *d_lin, uint32_t *d_bad, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(frame_index_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, d_xy, n, ox,
+                       oy, w, h, d_lin, d_bad);
+    return check_launch();
+}
+
+int launch_scatter_planes(const float *d_src, uint32_t n, const uint32_t *d_lin, float *d_dst, uint32_t n_dst,
+                          void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scatter_planes_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, d_src,
+                       n, d_lin, d_dst, n_dst);
     return check_launch();
 }
 

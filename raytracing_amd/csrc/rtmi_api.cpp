@@ -13,29 +13,17 @@
 #include <string>
 #include <vector>
 
-#include "../../include/rtmi.h"
 #include "bvh.h"
-#include "kernels.h"
 #include "obj_loader.h"
-#include "scene_build.h"
+#include "rtmi_internal.h"
 
 using rts::HostPrim;
+using rti::DeviceScope;
+using rti::fail;
 
 namespace {
 
 thread_local std::string g_error;
-
-int fail(int code, const std::string &msg) {
-    g_error = msg;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess)                                                                           \
-            return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
-    } while (0)
 
 // Device-time stopwatch of one call: intervals are bracketed by pairs of HIP events on one stream, and collect(),
 // called after the host has synchronised with that stream, adds every finished interval to its total and takes the
@@ -115,110 +103,12 @@ struct Stopwatch {
     }
 };
 
-// Makes a device current for the duration of one entry point and puts the caller's device back on the way out, so a
-// host that shares the thread with other HIP users (PyTorch, its own kernels) keeps its current device.
-struct DeviceScope {
-    int previous = -1;
-    hipError_t status = hipSuccess;
-    explicit DeviceScope(int ordinal) {
-        if (hipGetDevice(&previous) != hipSuccess) previous = -1;
-        if (previous != ordinal) status = hipSetDevice(ordinal);
-        else previous = -1; // already current: nothing to restore
-    }
-    ~DeviceScope() {
-        if (previous >= 0) (void)hipSetDevice(previous);
-    }
-    DeviceScope(const DeviceScope &) = delete;
-    DeviceScope &operator=(const DeviceScope &) = delete;
-};
-
-#define USE_DEVICE(dev)                                                                                  \
-    DeviceScope device_scope_((dev)->ordinal);                                                           \
-    if (device_scope_.status != hipSuccess)                                                              \
-    return fail(RTMI_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(device_scope_.status))
-
 } // namespace
 
-struct rtmi_device {
-    int ordinal = 0;
-    hipStream_t stream = nullptr;
-    std::mutex lock;
-    bool count_visits = false;
-    uint32_t *d_visits = nullptr; // two 64-bit counters
-    int n_cu = 256;
-    uint32_t *static_spill = nullptr; // this device's copy of the statically allocated stack-overflow buffer
-    size_t static_spill_words = 0;
-    std::atomic<int> refs{1}; // the handle itself + one per scene and film created on it
-};
-
-// A device outlives the scenes and films created on it, whatever order the caller destroys them in: the last
-// reference releases the stream and the counters.
-static void device_release(rtmi_device *dev) {
-    if (dev->refs.fetch_sub(1) != 1) return;
-    DeviceScope scope(dev->ordinal);
-    if (dev->stream) {
-        (void)hipStreamSynchronize(dev->stream);
-        (void)hipStreamDestroy(dev->stream);
-    }
-    if (dev->d_visits) (void)hipFree(dev->d_visits);
-    delete dev;
+int rti::fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
 }
-
-struct rtmi_scene {
-    rtmi_device *dev = nullptr;
-    std::vector<rtd::Material> materials;
-    std::vector<float> lights;
-    std::vector<HostPrim> prims;
-    std::vector<uint32_t> geom_material;
-    bool committed = false;
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    rtmi_scene_info info{};
-    rtd::F4 *d_nodes = nullptr;
-    rtd::F4 *d_prims = nullptr;
-    uint32_t *d_geom_material = nullptr;
-    rtd::Material *d_materials = nullptr;
-    uint32_t *d_spill = nullptr; // traversal stack overflow for a full resident grid; used on dev->stream only, under
-                                 // dev->lock (renders and rtmi_intersect)
-    size_t spill_bytes = 0;
-    uint32_t grid_blocks = 0;    // resident grid the spill buffers are sized for
-    rtd::SceneView view{};
-    // rtmi_intersect_device launches on caller-chosen streams, possibly several at once: each launch takes the next
-    // of a few spill buffers of its own and leaves an event behind; the launch that takes the buffer next waits for
-    // that event on its stream.  Buffers are created on first use and only for trees deeper than the LDS stack.
-    static constexpr int SPILL_SLOTS = 4;
-    struct SpillSlot {
-        uint32_t *d = nullptr;
-        hipEvent_t done = nullptr;
-        bool used = false;
-    };
-    std::mutex query_lock; // guards slots / next_slot
-    SpillSlot slots[SPILL_SLOTS];
-    unsigned next_slot = 0;
-    // staging of rtmi_intersect (host arrays), kept between calls and grown on demand; used under dev->lock
-    size_t stage_cap = 0;      // rays the device pair holds
-    rtmi_ray *d_stage_rays = nullptr;
-    rtmi_hit *d_stage_hits = nullptr;
-    size_t pinned_cap = 0;     // rays the pinned host pair holds (small batches only)
-    rtmi_ray *h_stage_rays = nullptr;
-    rtmi_hit *h_stage_hits = nullptr;
-};
-
-struct rtmi_film {
-    rtmi_device *dev = nullptr;
-    size_t n_pixels = 0;
-    uint32_t *d_xy = nullptr;
-    float *d_accum = nullptr;
-    bool own_accum = false;
-    // workspace, grown on demand
-    size_t cap_paths = 0;
-    float *d_state = nullptr;
-    float *d_hits = nullptr;
-    float *d_queue[2] = {nullptr, nullptr}; // ray payload planes, ping-pong by bounce parity
-    size_t cap_counters = 0;
-    uint32_t *d_counts = nullptr; // counts + work, cap_counters entries each
-    float *d_resolve = nullptr;
-    uint32_t *d_done = nullptr; // n_pixels flags + 1 count, see rtmi_render
-};
 
 namespace {
 
@@ -293,7 +183,7 @@ int rtmi_device_create(int hip_ordinal, rtmi_device **out) {
 
 void rtmi_device_destroy(rtmi_device *dev) {
     if (!dev) return;
-    device_release(dev);
+    rtmi_device_release(dev);
 }
 
 int rtmi_device_count_visits(rtmi_device *dev, int enable) {
@@ -338,7 +228,7 @@ void rtmi_scene_destroy(rtmi_scene *scene) {
         free_scene_device(scene);
     }
     delete scene;
-    device_release(dev);
+    rtmi_device_release(dev);
 }
 
 int rtmi_scene_insert_material(rtmi_scene *scene, const rtmi_material *mat, uint32_t *out_id) {
@@ -700,6 +590,61 @@ int rtmi_film_create(rtmi_device *dev, const uint32_t *xy, size_t n_pixels, floa
     return RTMI_OK;
 }
 
+int rtmi_film_create_frame(rtmi_device *dev, uint32_t offset_x, uint32_t offset_y, uint32_t width, uint32_t height,
+                           rtmi_film **out) {
+    if (!dev || !out) return fail(RTMI_ERR_ARG, "rtmi_film_create_frame: NULL argument");
+    if ((uint64_t)width * height >= (1ull << 30)) return fail(RTMI_ERR_LIMIT, "2^30 pixels or more in one film");
+    std::vector<uint32_t> xy((size_t)width * height * 2);
+    size_t k = 0;
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) {
+            xy[k++] = offset_x + x;
+            xy[k++] = offset_y + y;
+        }
+    if (int rc = rtmi_film_create(dev, xy.data(), xy.size() / 2, nullptr, out)) return rc;
+    (*out)->is_frame = true;
+    (*out)->frame_x = offset_x;
+    (*out)->frame_y = offset_y;
+    (*out)->frame_w = width;
+    (*out)->frame_h = height;
+    return RTMI_OK;
+}
+
+int rtmi_film_create_tiles(rtmi_device *dev, uint32_t offset_x, uint32_t offset_y, uint32_t width, uint32_t height,
+                           uint32_t grain, uint32_t first_tile, uint32_t tile_stride, uint32_t block_w, uint32_t block_h,
+                           rtmi_film **out) {
+    if (!dev || !out) return fail(RTMI_ERR_ARG, "rtmi_film_create_tiles: NULL argument");
+    if (grain == 0 || tile_stride == 0) return fail(RTMI_ERR_ARG, "rtmi_film_create_tiles: grain and stride must be > 0");
+    if ((block_w == 0) != (block_h == 0)) return fail(RTMI_ERR_ARG, "rtmi_film_create_tiles: give both block sides or none");
+    const uint32_t n_tiles = rtmi_tile_count(width, height, grain);
+    std::vector<uint32_t> xy;
+    for (uint32_t t = first_tile; t < n_tiles; t += tile_stride) {
+        uint32_t r[4];
+        if (int rc = rtmi_tile_get(offset_x, offset_y, width, height, grain, t, r)) return rc;
+        const uint32_t bw = block_w ? block_w : r[1] - r[0], bh = block_h ? block_h : 1;
+        for (uint32_t y0 = r[2]; y0 < r[3]; y0 += bh)
+            for (uint32_t x0 = r[0]; x0 < r[1]; x0 += bw)
+                for (uint32_t y = y0; y < std::min(y0 + bh, r[3]); ++y)
+                    for (uint32_t x = x0; x < std::min(x0 + bw, r[1]); ++x) {
+                        xy.push_back(x);
+                        xy.push_back(y);
+                    }
+        if (t > UINT32_MAX - tile_stride) break;
+    }
+    return rtmi_film_create(dev, xy.data(), xy.size() / 2, nullptr, out);
+}
+
+size_t rtmi_film_pixel_count(const rtmi_film *film) { return film ? film->n_pixels : 0; }
+
+int rtmi_film_pixels(rtmi_film *film, uint32_t *xy) {
+    if (!film || (film->n_pixels && !xy)) return fail(RTMI_ERR_ARG, "rtmi_film_pixels: NULL argument");
+    if (film->n_pixels == 0) return RTMI_OK;
+    std::lock_guard<std::mutex> g(film->dev->lock);
+    USE_DEVICE(film->dev);
+    HIP_TRY(hipMemcpy(xy, film->d_xy, film->n_pixels * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
 void rtmi_film_destroy(rtmi_film *film) {
     if (!film) return;
     DeviceScope scope(film->dev->ordinal);
@@ -713,9 +658,10 @@ void rtmi_film_destroy(rtmi_film *film) {
     if (film->d_counts) (void)hipFree(film->d_counts);
     if (film->d_resolve) (void)hipFree(film->d_resolve);
     if (film->d_done) (void)hipFree(film->d_done);
+    rtmi_gather_plan_free(film);
     rtmi_device *dev = film->dev;
     delete film;
-    device_release(dev);
+    rtmi_device_release(dev);
 }
 
 int rtmi_film_clear(rtmi_film *film) {
@@ -1033,6 +979,15 @@ int rtmi_tile_get(uint32_t offset_x, uint32_t offset_y, uint32_t width, uint32_t
     out[1] = offset_x + std::min(width, (x + 1) * grain);
     out[2] = offset_y + y * grain;
     out[3] = offset_y + std::min(height, (y + 1) * grain);
+    return RTMI_OK;
+}
+
+int rtmi_tile_partition(uint32_t n_tiles, uint32_t world, uint32_t rank, uint32_t *out_first, uint32_t *out_stride,
+                        uint32_t *out_count) {
+    if (world == 0 || rank >= world) return fail(RTMI_ERR_ARG, "rtmi_tile_partition: rank must be below world");
+    if (out_first) *out_first = rank;
+    if (out_stride) *out_stride = world;
+    if (out_count) *out_count = rank < n_tiles ? (n_tiles - rank + world - 1) / world : 0;
     return RTMI_OK;
 }
 

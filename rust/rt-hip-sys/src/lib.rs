@@ -35,6 +35,8 @@ pub struct RtmiRenderStats { pub rays: u64, pub paths: u64, pub passes: u32, pub
 pub enum RtmiDevice {}
 pub enum RtmiScene {}
 pub enum RtmiFilm {}
+pub enum RtmiComm {}
+pub const RTMI_COMM_ID_BYTES: usize = 128;
 
 extern "C" {
     pub fn rtmi_last_error() -> *const c_char;
@@ -53,6 +55,17 @@ extern "C" {
     pub fn rtmi_film_create(dev: *mut RtmiDevice, xy: *const u32, n_pixels: usize, d_accum: *mut f32, out: *mut *mut RtmiFilm) -> c_int;
     pub fn rtmi_film_destroy(film: *mut RtmiFilm);
     pub fn rtmi_film_resolve(film: *mut RtmiFilm, out: *mut f32, srgb: c_int) -> c_int;
+    pub fn rtmi_intersect_device(scene: *mut RtmiScene, d_rays: *const RtmiRay, d_hits: *mut RtmiHit, n: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn rtmi_intersect_device_static(scene: *mut RtmiScene, d_rays: *const RtmiRay, d_hits: *mut RtmiHit, n: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn rtmi_film_create_tiles(dev: *mut RtmiDevice, offset_x: u32, offset_y: u32, width: u32, height: u32, grain: u32, first_tile: u32, tile_stride: u32, block_w: u32, block_h: u32, out: *mut *mut RtmiFilm) -> c_int;
+    pub fn rtmi_film_create_frame(dev: *mut RtmiDevice, offset_x: u32, offset_y: u32, width: u32, height: u32, out: *mut *mut RtmiFilm) -> c_int;
+    pub fn rtmi_film_pixel_count(film: *const RtmiFilm) -> usize;
+    pub fn rtmi_film_pixels(film: *mut RtmiFilm, xy: *mut u32) -> c_int;
+    pub fn rtmi_tile_partition(n_tiles: u32, world: u32, rank: u32, out_first: *mut u32, out_stride: *mut u32, out_count: *mut u32) -> c_int;
+    pub fn rtmi_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn rtmi_comm_create(dev: *mut RtmiDevice, id: *const u8, rank: c_int, world: c_int, out: *mut *mut RtmiComm) -> c_int;
+    pub fn rtmi_comm_destroy(comm: *mut RtmiComm);
+    pub fn rtmi_film_gather(film: *mut RtmiFilm, comm: *mut RtmiComm, root: c_int, frame: *mut RtmiFilm) -> c_int;
     pub fn rtmi_render(scene: *mut RtmiScene, film: *mut RtmiFilm, camera: *const RtmiCamera, params: *const RtmiRenderParams, stats: *mut RtmiRenderStats) -> c_int;
 }
 
@@ -189,4 +202,36 @@ pub fn run_hip(scene: &CommittedHipScene, camera: &RtmiCamera, params: &RtmiRend
     unsafe { rtmi_film_destroy(film) };
     if rc2 != 0 { anyhow::bail!("rtmi_render: {}", last_error()); }
     Ok((out, stats))
+}
+
+/// One rank of a multi-GPU render (one thread or process per GPU, each with its own `HipDevice` and a full copy of the
+/// scene): renders this rank's interleaved share of the 32x32 tiles and gathers every rank's accumulators into rank 0's
+/// frame.  `id` comes from `rtmi_comm_unique_id` on one rank and reaches the others by any channel.  Returns the 15
+/// resolved channel planes of the whole frame on rank 0, an empty Vec elsewhere.
+pub fn run_hip_rank(scene: &CommittedHipScene, camera: &RtmiCamera, params: &RtmiRenderParams, tile_size: u32,
+                    id: &[u8; RTMI_COMM_ID_BYTES], rank: i32, world: i32) -> anyhow::Result<Vec<f32>> {
+    let dev = scene.scene.device.0;
+    let (w, h) = (camera.width, camera.height);
+    let fail = |what: &str| anyhow::anyhow!("{what}: {}", last_error());
+    unsafe {
+        let mut comm = std::ptr::null_mut();
+        if world > 1 && rtmi_comm_create(dev, id.as_ptr(), rank, world, &mut comm) != 0 { return Err(fail("rtmi_comm_create")); }
+        let mut film = std::ptr::null_mut();
+        if rtmi_film_create_tiles(dev, 0, 0, w, h, tile_size, rank as u32, world as u32, 8, 8, &mut film) != 0 { return Err(fail("rtmi_film_create_tiles")); }
+        let mut frame = std::ptr::null_mut();
+        if rank == 0 && rtmi_film_create_frame(dev, 0, 0, w, h, &mut frame) != 0 { return Err(fail("rtmi_film_create_frame")); }
+        let mut stats = RtmiRenderStats::default();
+        let mut rc = rtmi_render(scene.scene.raw, film, camera, params, &mut stats);
+        if rc == 0 { rc = rtmi_film_gather(film, comm, 0, frame); }
+        let mut out = Vec::new();
+        if rc == 0 && rank == 0 {
+            out = vec![0f32; 15 * (w as usize) * (h as usize)];
+            rc = rtmi_film_resolve(frame, out.as_mut_ptr(), 0);
+        }
+        let err = if rc != 0 { Some(fail("run_hip_rank")) } else { None };
+        rtmi_film_destroy(film);
+        if !frame.is_null() { rtmi_film_destroy(frame); }
+        if !comm.is_null() { rtmi_comm_destroy(comm); }
+        match err { Some(e) => Err(e), None => Ok(out) }
+    }
 }

@@ -160,3 +160,77 @@ def test_limits_are_reported(device, scene_classes):
     st = api.render(world, film, types.Camera.from_dimensions(8, 8), 1, max_depth=4096)
     assert st["paths"] == 64
     film.close()
+
+
+def test_tile_films_and_frame_gather(oracle, scene_classes, device):
+    """The multi-GPU pieces of the C ABI on one GPU: the tile share of every rank of a 3-rank job as films, rendered one
+    after the other, gathered into one frame (no communicator: films and frame on one device), must equal the
+    whole frame rendered at once, bit for bit; and the pixel lists are those of the Python partition."""
+    from raytracing_amd import api, types
+    from raytracing_amd import distributed as D
+    sg = api.HipScene(device)
+    scene_classes["cornell-box"].insert_into(sg)
+    world = sg.commit().into_world()
+    W, H, spp, grain = 150, 85, 3, 32  # ragged right and bottom tiles
+    cam = types.Camera.from_dimensions(W, H)
+    tiler = api.Tiler(0, 0, W, H, grain, grain)
+    n_tiles = tiler.tile_count()
+    frame = api.Film.frame(device, W, H)
+    assert np.array_equal(frame.xy, full_frame_xy(W, H))
+    ranks = 3
+    rays = 0
+    for r in range(ranks):
+        tiles = api.tile_partition(n_tiles, ranks, r)
+        assert list(tiles) == list(D.partition_tiles(n_tiles, ranks, r))
+        film = api.Film.for_tiles(device, tiler, tiles, (8, 8))
+        assert np.array_equal(film.xy, D.tile_pixels(tiler, tiles, (8, 8)))
+        rays += api.render(world, film, cam, spp)["rays"]
+        film.gather(None, frame)
+        film.gather(None, frame)  # the plan is reused
+        film.close()
+    whole = api.Film(device, full_frame_xy(W, H))
+    st = api.render(world, whole, cam, spp)
+    assert st["rays"] == rays
+    assert same_bits(frame.download(), whole.download()).all()
+    # row-major tiles without blocks, a window with an offset, more ranks than tiles
+    t2 = api.Tiler(7, 5, 40, 33, 32, 32)
+    f2 = api.Film.for_tiles(device, t2, api.tile_partition(t2.tile_count(), 2, 1), None)
+    assert np.array_equal(f2.xy, D.tile_pixels(t2, D.partition_tiles(t2.tile_count(), 2, 1)))
+    assert len(api.tile_partition(4, 8, 6)) == 0 and api.Film.for_tiles(device, t2, range(6, 4, 8)).n_pixels == 0
+    # a film with pixels outside the frame is refused
+    small = api.Film.frame(device, 16, 16)
+    with pytest.raises(api.RtmiError) as e:
+        f2.gather(None, small)
+    assert e.value.code == -1
+    for f in (frame, whole, f2, small):
+        f.close()
+
+
+def test_frame_gather_over_rccl_through_the_c_abi(scene_classes, device):
+    """rtmi_comm + rtmi_film_gather with a communicator: a job of one rank, whose send and receive go through RCCL
+    exactly as a peer's would (the root receives its own planes like everybody else's)."""
+    from raytracing_amd import api, types
+    sg = api.HipScene(device)
+    scene_classes["debug"].insert_into(sg)
+    world = sg.commit().into_world()
+    W, H, spp = 96, 54, 2
+    cam = types.Camera.from_dimensions(W, H)
+    tiler = api.Tiler(0, 0, W, H, 32, 32)
+    comm = api.Comm(device, api.Comm.unique_id(), 0, 1)
+    film = api.Film.for_tiles(device, tiler, api.tile_partition(tiler.tile_count(), 1, 0))
+    frame = api.Film.frame(device, W, H)
+    api.render(world, film, cam, spp)
+    film.gather(comm, frame)
+    first = frame.download()
+    whole = api.Film(device, full_frame_xy(W, H))
+    api.render(world, whole, cam, spp)
+    assert same_bits(first, whole.download()).all()
+    api.render(world, film, cam, spp, range(2, 4))  # a second frame through the same plan
+    film.gather(comm, frame)
+    api.render(world, whole, cam, spp, range(2, 4))
+    assert same_bits(frame.download(), whole.download()).all()
+    with pytest.raises(api.RtmiError):
+        film.gather(comm, frame, root=1)
+    for f in (film, frame, whole):
+        f.close()
+    comm.close()

@@ -390,3 +390,25 @@ def test_two_rank_tile_partition_and_gather(oracle, tmp_path):
     acc, _ = so.render(cam, oracle.make_params(spp=spp), xy)
     one = D.gather_frame(torch.from_numpy(acc), xy, W, H).numpy()
     assert same_bits(one, want).all()
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` outside a torch.distributed launch starts two ranks itself; with --dry-cpu --backend
+    gloo they run everything around the GPU work (rendezvous, tile partition, gather, timer reduction, one JSON line
+    from rank 0) on this machine, and a failing rank makes the launcher fail."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-cpu",
+           "--backend", "gloo", "--width", "150", "--height", "85"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_cpu"] and out["frame_ok"] and out["pixels"] == 150 * 85 and out["tiles"] == 15
+    # without --dry-cpu the ranks need GPUs: here they must fail, and the launcher must say so with its exit code
+    if not has_gpu():
+        r = subprocess.run(cmd[:8], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0
