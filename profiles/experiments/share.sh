@@ -1,4 +1,8 @@
 #!/bin/bash
-# Time of one rank's share of the headline frame for 1, 2, 4, 8 ranks, on one GPU (no gather): how much of the frame
-# does not shrink with the number of GPUs.
-for n in 1 2 4 8; do echo "share=1/$n $(RTMI_BENCH_SHARE=$n timeout -k 5 120 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-visits 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"gpu_ms_per_step_rank0": [0-9.]*' | tr '\n' ' ')"; done
+# Strong-scaling rehearsal on one GPU: the frame time of one rank's interleaved share of the tiles (no gather).
+# usage (on the GPU box): bash profiles/experiments/share.sh
+cd ${GRAFT_REPO_ROOT:-.}
+for n in 1 2 4 8; do
+  r=$(RTMI_BENCH_SHARE=$n timeout -k 10 120 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-visits 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), round(d['value'],1))") || exit 1
+  echo "share 1/$n: ms/frame, Mrays/s = $r"
+done

@@ -347,11 +347,19 @@ RT_DEV bool dielectric_sample_f(const Material &m, V3 wo, float u0, float u1, fl
     V3 wm = tr_sample_wm(alpha, wo, u0, u1);
     float r = fresnel_dielectric(dot(wo, wm), m.ior);
     float t = 1.0f - r;
-    if (u2 < r / (r + t)) {
+    // What the reflected and the refracted branch both evaluate is evaluated once, ahead of the branch: lanes of a wave
+    // rarely agree on the branch, so the wave runs both, and these are the expensive terms (divisions, square roots).
+    // Each value is the expression the branches use, operand for operand, so no result changes.
+    const float pr = r / (r + t);
+    const float d_wm = tr_d(alpha, wm);
+    const float lam_o = tr_lambda(alpha, wo);
+    const float dw = (1.0f / (1.0f + lam_o)) / fabsf(wo.z) * d_wm * fabsf(dot(wo, wm)); // tr_dw(alpha, wo, wm)
+    if (u2 < pr) {
         V3 wi = reflect(wo, wm);
         if (!same_hemisphere(wo, wi)) return false;
-        float f = tr_d(alpha, wm) * tr_g(alpha, wo, wi) * r / (4.0f * wi.z * wo.z);
-        float pdf = tr_dw(alpha, wo, wm) / (4.0f * fabsf(dot(wo, wm))) * r / (r + t);
+        const float g = 1.0f / (1.0f + lam_o + tr_lambda(alpha, wi)); // tr_g(alpha, wo, wi)
+        float f = d_wm * g * r / (4.0f * wi.z * wo.z);
+        float pdf = dw / (4.0f * fabsf(dot(wo, wm))) * r / (r + t);
         o.wi = wi;
         o.f = white(f);
         o.pdf = pdf;
@@ -364,8 +372,9 @@ RT_DEV bool dielectric_sample_f(const Material &m, V3 wo, float u0, float u1, fl
     float s = dot(wi, wm) + dot(wo, wm) / ior2;
     float denom = s * s;
     float dwm_dwi = fabsf(dot(wi, wm)) / denom;
-    float f = t * tr_d(alpha, wm) * tr_g(alpha, wo, wi) * fabsf(dot(wo, wm) * dot(wi, wm) / (wi.z * wo.z * denom));
-    float pdf = tr_dw(alpha, wo, wm) * dwm_dwi * t / (r + t);
+    const float g = 1.0f / (1.0f + lam_o + tr_lambda(alpha, wi)); // tr_g(alpha, wo, wi)
+    float f = t * d_wm * g * fabsf(dot(wo, wm) * dot(wi, wm) / (wi.z * wo.z * denom));
+    float pdf = dw * dwm_dwi * t / (r + t);
     o.wi = wi;
     o.f = white(f);
     o.pdf = pdf;

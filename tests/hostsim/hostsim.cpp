@@ -534,3 +534,129 @@ extern "C" void hs_wave_sim2(void *p, const Ray *rays, size_t n, int refill_belo
         }
     }
 }
+
+// Model of a block of four waves that share 256 ray slots kept in LDS: slot s belongs to lane position s % 64, and
+// every iteration a wave runs one phase (inner-node step or record test) in which each of its lanes works on a slot of
+// its lane position that waits for that phase and that no other wave holds.  A lane keeps its slot while the slot's ray
+// stays in the phase the wave runs; otherwise it puts the slot back and takes another (a swap: state written to and
+// read from LDS).  Waves are stepped round-robin.  cost = {node step, record step, refill pass, per iteration, swap};
+// out[0] wave-time (sum over waves), out[1] useful lane-time, out[2] node lane-steps, out[3] record lane-steps,
+// out[4] node iterations, out[5] record iterations, out[6] refill passes, out[7] iterations with a swap.
+extern "C" void hs_block_sim(void *p, const Ray *rays, size_t n, int refill_below, int n_waves, const double cost[5],
+                             double out[8]) {
+    Scene *s = (Scene *)p;
+    const double c_node = cost[0], c_leaf = cost[1], c_refill = cost[2], c_iter = cost[3], c_swap = cost[4];
+    struct Slot {
+        bool has = false;
+        int owner = -1; // wave holding it
+        V3 o, d;
+        Trav tr;
+        VecStack st;
+    };
+    for (int k = 0; k < 8; ++k) out[k] = 0.0;
+    const int W = n_waves;
+    size_t next = 0;
+    while (next < n) {
+        const size_t block_end = std::min(n, next + (size_t)4096 * W);
+        std::vector<Slot> S((size_t)64 * W);
+        std::vector<std::vector<int>> cur(W, std::vector<int>(64, -1)); // slot each wave-lane holds
+        auto phase_of = [](const Slot &x) { // 0 none/finished, 1 node, 2 leaf
+            if (!x.has || x.tr.cur == RT_EMPTY) return 0;
+            return (x.tr.cur & RT_LEAF) ? 2 : 1;
+        };
+        bool all_done = false;
+        while (!all_done) {
+            all_done = true;
+            for (int w = 0; w < W; ++w) {
+                // lanes of this wave that could work in each phase (their own slot or a free one at their position)
+                int can_node = 0, can_leaf = 0, live = 0, refillable = 0;
+                for (int l = 0; l < 64; ++l) {
+                    bool n_ok = false, l_ok = false, r_ok = false;
+                    for (int k = 0; k < W; ++k) {
+                        const Slot &x = S[(size_t)l + 64 * k];
+                        if (x.owner != -1 && x.owner != w) continue;
+                        const int ph = phase_of(x);
+                        n_ok |= ph == 1;
+                        l_ok |= ph == 2;
+                        r_ok |= ph == 0 && (x.has || next < block_end);
+                    }
+                    can_node += n_ok;
+                    can_leaf += l_ok;
+                    live += n_ok || l_ok;
+                    refillable += r_ok;
+                }
+                if (refillable > 64 - (refill_below < 0 ? 48 : refill_below) || live == 0) {
+                    // flush + refill the finished slots nobody holds (or that this wave holds) at every lane position
+                    bool any = false;
+                    for (int l = 0; l < 64; ++l)
+                        for (int k = 0; k < W; ++k) {
+                            Slot &x = S[(size_t)l + 64 * k];
+                            if (x.owner != -1 && x.owner != w) continue;
+                            if (x.has && x.tr.cur == RT_EMPTY) {
+                                x.has = false;
+                                any = true;
+                                if (x.owner == w) cur[w][l] = -1, x.owner = -1;
+                            }
+                            if (!x.has && next < block_end) {
+                                const Ray &r = rays[next++];
+                                x.o = mk(r.org[0], r.org[1], r.org[2]);
+                                x.d = mk(r.dir[0], r.dir[1], r.dir[2]);
+                                x.st = VecStack();
+                                trav_begin(s->view, x.o, x.d, INFINITY, x.tr);
+                                x.has = true;
+                                any = true;
+                            }
+                        }
+                    if (any) {
+                        out[0] += 64.0 * c_refill, out[6] += 1.0;
+                        all_done = false;
+                        continue; // next wave; this one decides its phase next round
+                    }
+                    if (live == 0) continue; // nothing left for this wave
+                }
+                all_done = false;
+                bool node_phase = can_leaf == 0 || (can_node > 0 && can_node >= can_leaf);
+                if (refill_below < 0) { // specialised waves: the last wave tests records whenever enough lanes can
+                    const int thr = -refill_below;
+                    if (w == W - 1) node_phase = can_leaf < thr && can_node > 0;
+                    else node_phase = can_node > 0 ? (can_leaf < 56 || can_node >= can_leaf) : false;
+                    if (can_leaf == 0) node_phase = true;
+                }
+                const int want = node_phase ? 1 : 2;
+                bool swapped = false;
+                int active = 0;
+                for (int l = 0; l < 64; ++l) {
+                    int c = cur[w][l];
+                    if (c >= 0 && phase_of(S[(size_t)c]) != want) {
+                        S[(size_t)c].owner = -1; // put back
+                        cur[w][l] = c = -1;
+                        swapped = true;
+                    }
+                    if (c < 0)
+                        for (int k = 0; k < W; ++k) {
+                            Slot &x = S[(size_t)l + 64 * k];
+                            if (x.owner == -1 && phase_of(x) == want) {
+                                x.owner = w;
+                                cur[w][l] = c = l + 64 * k;
+                                swapped = true;
+                                break;
+                            }
+                        }
+                    if (c < 0) continue;
+                    Slot &x = S[(size_t)c];
+                    ++active;
+                    if (node_phase)
+                        trav_node_step(s->view, RT_TNEAR, x.tr, x.st);
+                    else
+                        trav_leaf_step(s->view, x.o, x.d, RT_TNEAR, x.tr, x.st);
+                }
+                const double c_step = node_phase ? c_node : c_leaf;
+                out[0] += 64.0 * (c_step + c_iter + (swapped ? c_swap : 0.0));
+                out[1] += active * c_step;
+                out[node_phase ? 2 : 3] += active;
+                out[node_phase ? 4 : 5] += 1.0;
+                out[7] += swapped ? 1.0 : 0.0;
+            }
+        }
+    }
+}
