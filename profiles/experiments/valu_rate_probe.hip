@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void probe(float *out, unsigned long long *cyc
             if (KIND == 12) { asm volatile("v_mul_f32 %0, %0, %1\n v_add_f32 %1, %1, %2\n v_mul_f32 %2, %2, %3\n v_add_f32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
             if (KIND == 13) { asm volatile("v_cvt_f32_f16 %0, %1\n v_cvt_f32_f16 %1, %2\n v_cvt_f32_f16 %2, %3\n v_cvt_f32_f16 %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
             if (KIND == 14) { asm volatile("v_cvt_f32_u32 %0, %1\n v_cvt_f32_u32 %1, %2\n v_cvt_f32_u32 %2, %3\n v_cvt_f32_u32 %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+            if (KIND == 15) { asm volatile("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0\n v_cvt_f32_u32_sdwa %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n v_cvt_f32_u32_sdwa %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n v_cvt_f32_u32_sdwa %6, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(a), "+v"(ua), "=v"(b), "+v"(ub), "=v"(c), "+v"(ua), "=v"(d), "+v"(ub)); }
             if (KIND == 6) { asm volatile("v_min_f32 %0, %0, %1\n v_max_f32 %1, %1, %2\n v_min_f32 %2, %2, %3\n v_max_f32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
         }
     }
@@ -82,6 +83,7 @@ int main() {
         run<12>("v_mul_f32/v_add_f32", d_out, d_cyc, w);
         run<13>("v_cvt_f32_f16", d_out, d_cyc, w);
         run<14>("v_cvt_f32_u32", d_out, d_cyc, w);
+        run<15>("v_cvt_f32_u32_sdwa BYTE_n", d_out, d_cyc, w);
     }
     return 0;
 }
