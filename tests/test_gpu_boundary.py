@@ -234,3 +234,65 @@ def test_frame_gather_over_rccl_through_the_c_abi(scene_classes, device):
     for f in (film, frame, whole):
         f.close()
     comm.close()
+
+
+def test_c_host_runs(tmp_path, scene_classes, device):
+    """examples/abi_smoke.c (plain C99 against include/rtmi.h): scene, single-ray query, tile film, render, gather,
+    resolve -- and the same ray and path counts as the Python mirror gets for that scene and camera."""
+    import re
+    import subprocess
+    from raytracing_amd import api, types
+    from tests.test_host_logic import build_c_host
+    exe, env = build_c_host(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"rendered (\d+) paths, (\d+) rays", r.stdout)
+    sg = api.HipScene(device)
+    scene_classes["debug"].insert_into(sg)
+    world = sg.commit().into_world()
+    film = api.Film(device, full_frame_xy(64, 36))
+    st = api.render(world, film, types.Camera.from_dimensions(64, 36), 4)
+    film.close()
+    assert (int(m.group(1)), int(m.group(2))) == (st["paths"], st["rays"])
+
+
+def test_renders_and_queries_from_several_threads(oracle, scene_classes, device):
+    """Shape is Sync + Send (shape/mod.rs:3) and the reference calls it from every rayon worker: four host threads
+    render their own films and query the same committed scene at once; the calls serialise inside the library and
+    every thread gets what a lone call gets."""
+    import threading
+    from raytracing_amd import api, types, _lib
+    sg = api.HipScene(device)
+    scene_classes["cornell-box"].insert_into(sg)
+    world = sg.commit().into_world()
+    W, H, spp = 64, 36, 3
+    cam = types.Camera.from_dimensions(W, H)
+    xy = full_frame_xy(W, H)
+    rays = random_rays(_lib.RAY_DTYPE, 5000, 11)
+    rays["org"] = rays["org"] * 0.1 + np.array([0, 0, -0.5], np.float32)
+    film = api.Film(device, xy)
+    api.render(world, film, cam, spp)
+    want_acc, want_hits = film.download(), world.intersect(rays)
+    film.close()
+    out, errors = {}, []
+
+    def work(k):
+        try:
+            f = api.Film(device, xy)
+            for _ in range(3):
+                f.clear()
+                api.render(world, f, cam, spp)
+                hits = world.intersect(rays)
+            out[k] = (f.download(), hits)
+            f.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(4):
+        assert same_bits(out[k][0], want_acc).all() and out[k][1].tobytes() == want_hits.tobytes()

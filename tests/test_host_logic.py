@@ -412,3 +412,27 @@ def test_bench_launches_its_own_ranks(tmp_path):
     if not has_gpu():
         r = subprocess.run(cmd[:8], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode != 0
+
+
+def build_c_host(tmp_path):
+    """examples/abi_smoke.c, a host in plain C99 against include/rtmi.h and librtmi.so alone."""
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "abi_smoke.c"), "-L" + os.path.join(ROOT, "raytracing_amd"),
+                        "-lrtmi", "-lm", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "raytracing_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    return exe, env
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """The boundary is a C ABI: the header compiles as strict C99 and a C program links against the library with no
+    C++ or Python in between.  Without a GPU the program must stop at its first call with the library's error."""
+    import subprocess
+    exe, env = build_c_host(tmp_path)
+    if has_gpu():
+        pytest.skip("a GPU is present: the run is covered by the GPU tests")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
