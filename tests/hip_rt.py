@@ -29,6 +29,12 @@ def hip():
             "hipGetDevice": [C.POINTER(C.c_int)],
             "hipGetDeviceCount": [C.POINTER(C.c_int)],
             "hipMemGetInfo": [C.POINTER(sz), C.POINTER(sz)],
+            "hipStreamBeginCapture": [vp, C.c_int],
+            "hipStreamEndCapture": [vp, C.POINTER(vp)],
+            "hipGraphInstantiate": [C.POINTER(vp), vp, vp, vp, sz],
+            "hipGraphLaunch": [vp, vp],
+            "hipGraphExecDestroy": [vp],
+            "hipGraphDestroy": [vp],
         }
         for name, args in sig.items():
             fn = getattr(L, name)

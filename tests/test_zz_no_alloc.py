@@ -77,6 +77,47 @@ def test_static_entry_point_matches_the_allocating_one(device, scene_classes, de
     stream.destroy()
 
 
+def test_static_entry_point_under_graph_capture(device):
+    """What the entry point is for: captured into a HIP graph (global capture mode, under which a device allocation
+    from any thread is an error), instantiated, and launched twice; every launch of the graph gives the hits of a
+    direct call, on a tree deep enough to use the static stack-overflow buffer."""
+    from raytracing_amd import _lib, api
+    from tests import hip_rt
+    hip = hip_rt.hip()
+    sg = api.HipScene(device)
+    v, idx = _soup(40000, 21)
+    sg.insert_mesh(0, v, idx)
+    world = sg.commit().into_world()
+    assert world.info()["stack_need"] > 24
+    m = 50000
+    rays = _rays(_lib.RAY_DTYPE, m, 77)
+    want = world.intersect(rays)
+    d_rays = hip_rt.DeviceBuffer.from_array(rays)
+    d_hits = hip_rt.DeviceBuffer(m * _lib.HIT_DTYPE.itemsize)
+    stream = hip_rt.Stream()
+    sp = C.c_void_p(stream.handle)
+    hip_rt.ok(hip.hipStreamBeginCapture(sp, 0))  # hipStreamCaptureModeGlobal
+    try:
+        world.intersect_device_static(d_rays.ptr, d_hits.ptr, m, sp)
+    finally:
+        graph = C.c_void_p()
+        rc = hip.hipStreamEndCapture(sp, C.byref(graph))
+    hip_rt.ok(rc)
+    assert graph.value
+    gexec = C.c_void_p()
+    hip_rt.ok(hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0))
+    for _ in range(2):
+        d_hits.fill(0xEE)  # nothing ran at capture time, and every launch writes every hit
+        hip_rt.ok(hip.hipGraphLaunch(gexec, sp))
+        stream.synchronize()
+        assert d_hits.download(_lib.HIT_DTYPE).tobytes() == want.tobytes()
+    hip_rt.ok(hip.hipGraphExecDestroy(gexec))
+    hip_rt.ok(hip.hipGraphDestroy(graph))
+    d_rays.free()
+    d_hits.free()
+    stream.destroy()
+
+
 def test_static_entry_point_argument_errors(device, scene_classes):
     from raytracing_amd import api
     sg = api.HipScene(device)
