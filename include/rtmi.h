@@ -306,9 +306,12 @@ void rtmi_comm_destroy(rtmi_comm *comm);
  * `root`, at the pixels' positions there.  Collective: every rank of `comm` calls it with its own film; `frame` is
  * used on the root only (a film made by rtmi_film_create_frame on the root's device; NULL elsewhere) and pixels no
  * rank sent keep their old values.  Nothing is reduced: ranks must own disjoint pixels.  comm == NULL is the
- * single-GPU case (film and frame on one device).  The first call for a (film, comm, root, frame) combination also
- * exchanges the pixel lists; later calls move only the 88 bytes per pixel, each peer straight to the root.
- * Synchronous: returns when the frame is complete on the root. */
+ * single-GPU case (film and frame on one device).  The first call for a (film, comm, root) combination also sends
+ * the pixel lists to the root; later calls move only the 88 bytes per pixel, each peer straight to the root, after a
+ * 16-byte status exchange in which the ranks tell each other whether they can take part: if one of them cannot (a bad
+ * argument, a film with pixels outside the frame, no memory for the root's staging), every rank returns an error
+ * (the failing rank its own, the others RTMI_ERR_STATE) and nothing has been exchanged.  The root may gather into a
+ * different frame from call to call.  Synchronous: returns when the frame is complete on the root. */
 int rtmi_film_gather(rtmi_film *film, rtmi_comm *comm, int root, rtmi_film *frame);
 
 #ifdef __cplusplus

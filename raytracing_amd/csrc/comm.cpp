@@ -4,7 +4,9 @@
 // The reference is a single process on shared memory (crates/rt-cli/src/executor.rs:307-330): its tiles write into
 // one Vec of RaySeries.  Here each rank renders its own tiles into its own film, and the only exchange step of a
 // frame is this gather: tiles are disjoint, so nothing is reduced, and peers send straight to the root (xGMI is point
-// to point: 7 peers on 7 links, no ring).
+// to point: 7 peers on 7 links, no ring).  A gather starts with a 16-byte all-gather of every rank's status, so an
+// argument error or a failed allocation on one rank makes every rank return an error instead of leaving the others
+// waiting in a send, and so that all ranks agree on when the pixel lists have to be exchanged again.
 //
 // RCCL is opened at run time, by soname, when the first communicator is made: a single-GPU host needs no RCCL, and
 // a process that already carries a copy (PyTorch does) shares it instead of loading a second one.
@@ -103,26 +105,36 @@ struct rtmi_comm {
     rtmi_device *dev = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    unsigned long long *d_status = nullptr; // 2 * (world + 1) words for the status rounds of rtmi_film_gather
 };
 
-// What a (source film, communicator, root, frame) combination keeps between gathers: on the root, every rank's pixel
-// count, frame positions and a staging buffer for its accumulator planes.
+// What a (film, communicator, root) combination keeps between gathers.  On the root: every rank's pixel count and
+// pixel list (received once), a staging buffer for its accumulator planes, and for the frame last gathered into the
+// position of every pixel in it.
 struct rtmi_gather_plan {
     const rtmi_comm *comm = nullptr;
-    const rtmi_film *frame = nullptr; // root only
     int root = 0;
+    std::vector<size_t> counts;      // root only: pixels of every rank
+    std::vector<uint32_t *> d_xy;    // root only: pixel list of every rank (the film's own list when comm is null)
+    bool owns_xy = false;
+    std::vector<float *> d_stage;    // root only, comm only: RTMI_ACCUM_PLANES planes of counts[r] floats
+    // frame-specific, root only
+    const rtmi_film *frame = nullptr;
     uint32_t fx = 0, fy = 0, fw = 0, fh = 0;
-    std::vector<size_t> counts;       // root only: pixels of every rank
-    std::vector<uint32_t *> d_lin;    // root only: frame position of every pixel of every rank
-    std::vector<float *> d_stage;     // root only: RTMI_ACCUM_PLANES planes of counts[r] floats
+    std::vector<uint32_t *> d_lin;   // frame position of every pixel of every rank
     void release() {
         for (uint32_t *p : d_lin)
             if (p) (void)hipFree(p);
         for (float *p : d_stage)
             if (p) (void)hipFree(p);
+        if (owns_xy)
+            for (uint32_t *p : d_xy)
+                if (p) (void)hipFree(p);
         d_lin.clear();
         d_stage.clear();
+        d_xy.clear();
         counts.clear();
+        frame = nullptr;
     }
 };
 
@@ -135,101 +147,70 @@ void rtmi_gather_plan_free(rtmi_film *film) {
 
 namespace {
 
-// Builds film->plan for (comm, root, frame).  Collective when comm is set: every rank calls it at the same point.
-int build_plan(rtmi_film *film, rtmi_comm *comm, int root, rtmi_film *frame) {
-    rtmi_device *dev = film->dev;
-    hipStream_t stream = dev->stream;
-    rtmi_gather_plan_free(film);
-    rtmi_gather_plan *plan = new rtmi_gather_plan();
-    film->plan = plan;
-    plan->comm = comm;
-    plan->root = root;
-    const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
-    const bool is_root = rank == root;
-    if (is_root) {
-        plan->frame = frame;
-        plan->fx = frame->frame_x;
-        plan->fy = frame->frame_y;
-        plan->fw = frame->frame_w;
-        plan->fh = frame->frame_h;
-    }
-    // 1. every rank's pixel count, to every rank
-    std::vector<unsigned long long> counts((size_t)world, 0ull);
-    counts[(size_t)rank] = film->n_pixels;
-    unsigned long long *d_counts = nullptr;
-    if (comm) {
-        HIP_TRY(hipMalloc((void **)&d_counts, sizeof(unsigned long long) * (size_t)(world + 1)));
-        const unsigned long long mine = film->n_pixels;
-        hipError_t e = hipMemcpyAsync(d_counts + world, &mine, sizeof mine, hipMemcpyHostToDevice, stream);
-        ncclResult_t r = ncclSuccess;
-        if (e == hipSuccess) r = rccl()->AllGather(d_counts + world, d_counts, 1, ncclUint64, comm->comm, stream);
-        if (e == hipSuccess && r == ncclSuccess)
-            e = hipMemcpyAsync(counts.data(), d_counts, sizeof(unsigned long long) * (size_t)world,
-                               hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_counts);
-        if (r != ncclSuccess) return fail(RTMI_ERR_DEVICE, std::string("ncclAllGather: ") + rccl()->GetErrorString(r));
-        if (e != hipSuccess) return fail(RTMI_ERR_DEVICE, std::string("gather plan: ") + hipGetErrorString(e));
-    }
-    // 2. every rank's pixel list to the root, which turns it into frame positions
-    std::vector<uint32_t *> d_xy((size_t)world, nullptr);
+constexpr unsigned long long FLAG_ERROR = 1, FLAG_EXCHANGE = 2;
+
+// One status round: every rank contributes two words and learns everybody's.  This is what keeps the ranks of a
+// gather in step: an argument error or a failed allocation on one rank is seen by all of them before any of them
+// commits to a send or a receive that the failing rank would not match.
+int status_round(rtmi_comm *comm, hipStream_t stream, unsigned long long w0, unsigned long long w1,
+                 std::vector<unsigned long long> &all) {
+    const size_t world = (size_t)comm->world;
+    unsigned long long mine[2] = {w0, w1};
+    all.assign(2 * world, 0ull);
+    HIP_TRY(hipMemcpyAsync(comm->d_status + 2 * world, mine, sizeof mine, hipMemcpyHostToDevice, stream));
+    NCCL_TRY(rccl()->AllGather(comm->d_status + 2 * world, comm->d_status, 2, ncclUint64, comm->comm, stream));
+    HIP_TRY(hipMemcpyAsync(all.data(), comm->d_status, sizeof(unsigned long long) * 2 * world, hipMemcpyDeviceToHost,
+                           stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return RTMI_OK;
+}
+
+// First rank whose flags word has `bit` set, or -1.
+int first_with(const std::vector<unsigned long long> &all, unsigned long long bit) {
+    for (size_t r = 0; 2 * r + 1 < all.size(); ++r)
+        if (all[2 * r + 1] & bit) return (int)r;
+    return -1;
+}
+
+// Root only: positions of every rank's pixels in `frame`; fails when a pixel lies outside it.  Local (no
+// communication): the pixel lists are already here.
+int index_frame(rtmi_gather_plan *plan, const rtmi_film *frame, hipStream_t stream) {
+    const size_t world = plan->counts.size();
+    for (uint32_t *p : plan->d_lin)
+        if (p) (void)hipFree(p);
+    plan->d_lin.assign(world, nullptr);
+    plan->frame = nullptr;
     uint32_t *d_bad = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_bad, sizeof(uint32_t)));
     int rc = RTMI_OK;
-    auto cleanup = [&] {
-        for (int r = 0; r < world; ++r)
-            if (d_xy[(size_t)r] && !(r == rank && !comm)) (void)hipFree(d_xy[(size_t)r]);
-        if (d_bad) (void)hipFree(d_bad);
-    };
-    if (is_root) {
-        plan->counts.assign(counts.begin(), counts.end());
-        plan->d_lin.assign((size_t)world, nullptr);
-        plan->d_stage.assign((size_t)world, nullptr);
-        HIP_TRY(hipMalloc((void **)&d_bad, sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream));
-        for (int r = 0; r < world && rc == RTMI_OK; ++r) {
-            const size_t n = plan->counts[(size_t)r];
-            if (n == 0) continue;
-            hipError_t e = hipMalloc((void **)&plan->d_lin[(size_t)r], n * sizeof(uint32_t));
-            if (e == hipSuccess && comm) e = hipMalloc((void **)&d_xy[(size_t)r], n * 2 * sizeof(uint32_t));
-            if (e == hipSuccess && comm)
-                e = hipMalloc((void **)&plan->d_stage[(size_t)r], n * RTMI_ACCUM_PLANES * sizeof(float));
-            if (e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("gather plan: ") + hipGetErrorString(e));
-        }
-        if (!comm) d_xy[0] = film->d_xy;
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream);
+    for (size_t r = 0; r < world && e == hipSuccess && rc == RTMI_OK; ++r) {
+        const size_t n = plan->counts[r];
+        if (n == 0) continue;
+        e = hipMalloc((void **)&plan->d_lin[r], n * sizeof(uint32_t));
+        if (e == hipSuccess && rtk::launch_frame_index(plan->d_xy[r], (uint32_t)n, frame->frame_x, frame->frame_y,
+                                                       frame->frame_w, frame->frame_h, plan->d_lin[r], d_bad, stream))
+            rc = fail(RTMI_ERR_DEVICE, "frame index kernel launch failed");
     }
-    if (comm) {
-        // the exchange runs even when the root failed to allocate, so that no peer is left waiting in a send; the
-        // root then receives nothing useful and reports its error afterwards
-        ncclResult_t r = rccl()->GroupStart();
-        if (r == ncclSuccess && film->n_pixels)
-            r = rccl()->Send(film->d_xy, film->n_pixels * 2, ncclUint32, root, comm->comm, stream);
-        if (is_root && rc == RTMI_OK)
-            for (int p = 0; p < world && r == ncclSuccess; ++p)
-                if (plan->counts[(size_t)p])
-                    r = rccl()->Recv(d_xy[(size_t)p], plan->counts[(size_t)p] * 2, ncclUint32, p, comm->comm, stream);
-        ncclResult_t r2 = rccl()->GroupEnd();
-        if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess && rc == RTMI_OK)
-            rc = fail(RTMI_ERR_DEVICE, std::string("gather plan exchange: ") + rccl()->GetErrorString(r));
-    }
-    if (is_root && rc == RTMI_OK) {
-        for (int r = 0; r < world && rc == RTMI_OK; ++r)
-            if (rtk::launch_frame_index(d_xy[(size_t)r], (uint32_t)plan->counts[(size_t)r], plan->fx, plan->fy, plan->fw,
-                                        plan->fh, plan->d_lin[(size_t)r], d_bad, stream))
-                rc = fail(RTMI_ERR_DEVICE, "frame index kernel launch failed");
-        uint32_t bad = 0;
-        if (rc == RTMI_OK) {
-            hipError_t e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("gather plan: ") + hipGetErrorString(e));
-            else if (bad) rc = fail(RTMI_ERR_ARG, "rtmi_film_gather: a film holds pixels outside the frame");
-        }
-    }
-    hipError_t e = hipStreamSynchronize(stream);
-    cleanup();
-    if (rc == RTMI_OK && e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("gather plan: ") + hipGetErrorString(e));
-    if (rc != RTMI_OK) rtmi_gather_plan_free(film);
-    return rc;
+    uint32_t bad = 0;
+    if (e == hipSuccess && rc == RTMI_OK) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, stream);
+    hipError_t e2 = hipStreamSynchronize(stream);
+    (void)hipFree(d_bad);
+    if (rc == RTMI_OK && (e != hipSuccess || e2 != hipSuccess))
+        rc = fail(RTMI_ERR_DEVICE, std::string("frame index: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    if (rc == RTMI_OK && bad) rc = fail(RTMI_ERR_ARG, "rtmi_film_gather: a film holds pixels outside the frame");
+    if (rc != RTMI_OK) return rc;
+    plan->frame = frame;
+    plan->fx = frame->frame_x;
+    plan->fy = frame->frame_y;
+    plan->fw = frame->frame_w;
+    plan->fh = frame->frame_h;
+    return RTMI_OK;
+}
+
+bool frame_indexed(const rtmi_gather_plan *plan, const rtmi_film *frame) {
+    return plan->frame == frame && plan->fx == frame->frame_x && plan->fy == frame->frame_y &&
+           plan->fw == frame->frame_w && plan->fh == frame->frame_h;
 }
 
 } // namespace
@@ -256,12 +237,19 @@ int rtmi_comm_create(rtmi_device *dev, const unsigned char id[RTMI_COMM_ID_BYTES
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     ncclComm_t c = nullptr;
-    NCCL_TRY(rccl()->CommInitRank(&c, world, u, rank));
+    unsigned long long *d_status = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_status, sizeof(unsigned long long) * 2 * (size_t)(world + 1)));
+    ncclResult_t nr = rccl()->CommInitRank(&c, world, u, rank);
+    if (nr != ncclSuccess) {
+        (void)hipFree(d_status);
+        return fail(RTMI_ERR_DEVICE, std::string("ncclCommInitRank: ") + rccl()->GetErrorString(nr));
+    }
     rtmi_comm *comm = new rtmi_comm();
     comm->dev = dev;
     comm->comm = c;
     comm->rank = rank;
     comm->world = world;
+    comm->d_status = d_status;
     dev->refs.fetch_add(1);
     *out = comm;
     return RTMI_OK;
@@ -274,6 +262,7 @@ void rtmi_comm_destroy(rtmi_comm *comm) {
         rti::DeviceScope scope(dev->ordinal);
         (void)hipStreamSynchronize(dev->stream);
         if (rccl() && comm->comm) (void)rccl()->CommDestroy(comm->comm);
+        if (comm->d_status) (void)hipFree(comm->d_status);
     }
     delete comm;
     rtmi_device_release(dev);
@@ -283,35 +272,116 @@ int rtmi_film_gather(rtmi_film *film, rtmi_comm *comm, int root, rtmi_film *fram
     if (!film) return fail(RTMI_ERR_ARG, "rtmi_film_gather: film is NULL");
     const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
     if (root < 0 || root >= world) return fail(RTMI_ERR_ARG, "rtmi_film_gather: root is not a rank");
-    if (comm && comm->dev != film->dev) return fail(RTMI_ERR_ARG, "rtmi_film_gather: film and communicator on different devices");
+    if (comm && comm->dev != film->dev)
+        return fail(RTMI_ERR_ARG, "rtmi_film_gather: film and communicator on different devices");
     const bool is_root = rank == root;
-    // argument errors on the root must not leave the peers waiting: they are reported before anything is sent only
-    // when they cannot differ between ranks; a bad frame on the root is the caller's to avoid
+    // What only this rank can see wrong with its arguments.  With a communicator it is not returned at once but told to
+    // the other ranks in the status round below, so that all of them leave the call together.
+    std::string local_error;
     if (is_root) {
-        if (!frame) return fail(RTMI_ERR_ARG, "rtmi_film_gather: the root needs a frame");
-        if (!frame->is_frame) return fail(RTMI_ERR_ARG, "rtmi_film_gather: frame was not made by rtmi_film_create_frame");
-        if (frame->dev != film->dev) return fail(RTMI_ERR_ARG, "rtmi_film_gather: film and frame on different devices");
-        if (frame == film) return fail(RTMI_ERR_ARG, "rtmi_film_gather: film and frame are the same object");
+        if (!frame) local_error = "the root needs a frame";
+        else if (!frame->is_frame) local_error = "frame was not made by rtmi_film_create_frame";
+        else if (frame->dev != film->dev) local_error = "film and frame on different devices";
+        else if (frame == film) local_error = "film and frame are the same object";
     }
+    if (!comm && !local_error.empty()) return fail(RTMI_ERR_ARG, "rtmi_film_gather: " + local_error);
     rtmi_device *dev = film->dev;
     std::lock_guard<std::mutex> g(dev->lock);
     USE_DEVICE(dev);
     hipStream_t stream = dev->stream;
     rtmi_gather_plan *plan = film->plan;
-    const bool stale = !plan || plan->comm != comm || plan->root != root ||
-                       (is_root && (plan->frame != frame || plan->fx != frame->frame_x || plan->fy != frame->frame_y ||
-                                    plan->fw != frame->frame_w || plan->fh != frame->frame_h));
-    if (stale) {
-        if (int rc = build_plan(film, comm, root, frame)) return rc;
-        plan = film->plan;
-    }
+    bool need_exchange = !plan || plan->comm != comm || plan->root != root;
+
     if (!comm) {
+        // one rank, film and frame on one device: the film's own pixel list, no staging
+        if (need_exchange) {
+            rtmi_gather_plan_free(film);
+            plan = film->plan = new rtmi_gather_plan();
+            plan->root = root;
+            plan->counts.assign(1, film->n_pixels);
+            plan->d_xy.assign(1, film->d_xy);
+        }
+        if (!frame_indexed(plan, frame))
+            if (int rc = index_frame(plan, frame, stream)) return rc;
         if (rtk::launch_scatter_planes(film->d_accum, (uint32_t)film->n_pixels, plan->d_lin[0], frame->d_accum,
                                        (uint32_t)frame->n_pixels, stream))
             return fail(RTMI_ERR_DEVICE, "scatter kernel launch failed");
         HIP_TRY(hipStreamSynchronize(stream));
         return RTMI_OK;
     }
+
+    // a frame the root already holds every pixel list for is indexed (and checked) before the ranks compare notes
+    int local_code = local_error.empty() ? RTMI_OK : RTMI_ERR_ARG;
+    if (is_root && local_code == RTMI_OK && !need_exchange && !frame_indexed(plan, frame)) {
+        local_code = index_frame(plan, frame, stream);
+        if (local_code != RTMI_OK) local_error = rtmi_last_error();
+    }
+    std::vector<unsigned long long> all;
+    if (int rc = status_round(comm, stream, film->n_pixels,
+                              (local_code != RTMI_OK ? FLAG_ERROR : 0) | (need_exchange ? FLAG_EXCHANGE : 0), all))
+        return rc;
+    auto report = [&](int bad_rank) {
+        if (bad_rank == rank) return fail(local_code != RTMI_OK ? local_code : RTMI_ERR_DEVICE, "rtmi_film_gather: " + local_error);
+        return fail(RTMI_ERR_STATE, "rtmi_film_gather: rank " + std::to_string(bad_rank) + " could not take part; nothing was exchanged");
+    };
+    int bad_rank = first_with(all, FLAG_ERROR);
+    if (bad_rank >= 0) return report(local_code != RTMI_OK ? rank : bad_rank);
+
+    if (first_with(all, FLAG_EXCHANGE) >= 0) {
+        // some rank is new to this (film, communicator, root) combination: every rank sends its pixel list again
+        rtmi_gather_plan_free(film);
+        plan = film->plan = new rtmi_gather_plan();
+        plan->comm = comm;
+        plan->root = root;
+        if (is_root) {
+            plan->owns_xy = true;
+            plan->counts.resize((size_t)world);
+            plan->d_xy.assign((size_t)world, nullptr);
+            plan->d_stage.assign((size_t)world, nullptr);
+            hipError_t e = hipSuccess;
+            for (int r = 0; r < world && e == hipSuccess; ++r) {
+                const size_t n = plan->counts[(size_t)r] = (size_t)all[2 * (size_t)r];
+                if (n == 0) continue;
+                e = hipMalloc((void **)&plan->d_xy[(size_t)r], n * 2 * sizeof(uint32_t));
+                if (e == hipSuccess) e = hipMalloc((void **)&plan->d_stage[(size_t)r], n * RTMI_ACCUM_PLANES * sizeof(float));
+            }
+            if (e != hipSuccess) {
+                local_code = RTMI_ERR_DEVICE;
+                local_error = std::string("staging allocation on the root: ") + hipGetErrorString(e);
+            }
+        }
+        std::vector<unsigned long long> ok;
+        int rc = status_round(comm, stream, 0, local_code != RTMI_OK ? FLAG_ERROR : 0, ok);
+        if (rc == RTMI_OK && (bad_rank = first_with(ok, FLAG_ERROR)) >= 0) rc = report(bad_rank);
+        if (rc != RTMI_OK) {
+            rtmi_gather_plan_free(film);
+            return rc;
+        }
+        ncclResult_t r = rccl()->GroupStart();
+        if (r == ncclSuccess && film->n_pixels)
+            r = rccl()->Send(film->d_xy, film->n_pixels * 2, ncclUint32, root, comm->comm, stream);
+        if (is_root)
+            for (int p = 0; p < world && r == ncclSuccess; ++p)
+                if (plan->counts[(size_t)p])
+                    r = rccl()->Recv(plan->d_xy[(size_t)p], plan->counts[(size_t)p] * 2, ncclUint32, p, comm->comm, stream);
+        ncclResult_t r2 = rccl()->GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        hipError_t e = hipStreamSynchronize(stream);
+        if (r != ncclSuccess || e != hipSuccess) {
+            rtmi_gather_plan_free(film);
+            return fail(RTMI_ERR_DEVICE, std::string("rtmi_film_gather, pixel lists: ") +
+                                             (r != ncclSuccess ? rccl()->GetErrorString(r) : hipGetErrorString(e)));
+        }
+        // the root indexes its frame with the new lists; whether that worked is the third thing the ranks agree on
+        if (is_root) {
+            local_code = index_frame(plan, frame, stream);
+            if (local_code != RTMI_OK) local_error = rtmi_last_error();
+        }
+        rc = status_round(comm, stream, 0, local_code != RTMI_OK ? FLAG_ERROR : 0, ok);
+        if (rc == RTMI_OK && (bad_rank = first_with(ok, FLAG_ERROR)) >= 0) rc = report(bad_rank);
+        if (rc != RTMI_OK) return rc; // the lists stay: a call with a frame that fits needs no new exchange
+    }
+
     // every rank, the root included, sends its planes to the root; the root receives one message per rank
     ncclResult_t r = rccl()->GroupStart();
     if (r == ncclSuccess && film->n_pixels)

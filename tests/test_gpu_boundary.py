@@ -231,7 +231,22 @@ def test_frame_gather_over_rccl_through_the_c_abi(scene_classes, device):
     assert same_bits(frame.download(), whole.download()).all()
     with pytest.raises(api.RtmiError):
         film.gather(comm, frame, root=1)
-    for f in (film, frame, whole):
+    # errors only the root can see go through the ranks' status exchange: a frame the film does not fit in, then a
+    # frame it fits in again (no new exchange of pixel lists), then a window with an offset
+    small = api.Film.frame(device, 32, 32)
+    with pytest.raises(api.RtmiError) as e:
+        film.gather(comm, small)
+    assert e.value.code == -1 and "outside the frame" in str(e.value)
+    with pytest.raises(api.RtmiError) as e:
+        film.gather(comm, None)
+    assert e.value.code == -1
+    wide = api.Film.frame(device, W + 8, H + 4)
+    film.gather(comm, wide)
+    got = wide.download().reshape(22, H + 4, W + 8)
+    assert same_bits(got[:, :H, :W].reshape(22, -1), whole.download()).all() and (got[:, H:, :] == 0).all()
+    film.gather(comm, frame)
+    assert same_bits(frame.download(), whole.download()).all()
+    for f in (film, frame, whole, small, wide):
         f.close()
     comm.close()
 
