@@ -20,6 +20,9 @@ constexpr int PIXEL_BLOCK = 64;     // pixels whose samples are adjacent in path
 constexpr int SEGMENTS = 8;         // queue segments, one per XCD (each XCD has its own L2)
 constexpr int COUNTER_STRIDE = 64;  // uint32 slots between two counters: every counter has a 256-byte line to itself
 constexpr int LDS_STACK = 24;       // stack entries kept in LDS per lane; deeper entries spill to global memory
+constexpr int QUEUE_STACK = 13;     // the same in the traversal kernel that defers its record tests (LDS also holds its queue)
+constexpr int QUEUE_CAP = 128;      // record tests a wave of that kernel can have waiting (a power of two)
+constexpr int SPILL_FROM = QUEUE_STACK < LDS_STACK ? QUEUE_STACK : LDS_STACK; // first stack entry that may spill
 
 struct RayAoS {
     float org[3];
@@ -56,7 +59,7 @@ struct RenderArgs {
     uint32_t *counts;       // counts[(d * SEGMENTS + x) * COUNTER_STRIDE] = live paths of segment x entering bounce d
                             // (d >= 1); zeroed before the pass
     uint32_t *work;         // work[(d * SEGMENTS + x) * COUNTER_STRIDE] = next unclaimed position of that queue; zeroed
-    uint32_t *spill;        // traversal stack overflow: (stack_need - LDS_STACK) entries per launched thread
+    uint32_t *spill;        // traversal stack overflow: (stack_need - SPILL_FROM) entries per launched thread
     uint32_t *visit_counters; // optional: [0] node visits, [1] primitive tests (64-bit pairs lo/hi), may be null
     uint32_t *pixel_done;     // optional: pixel_done[i] != 0 = pixel i is precise enough and takes no more samples in
                               // this call (its paths are neither generated nor accumulated); pixel_done[n_pixels]
@@ -69,6 +72,8 @@ struct RenderArgs {
     uint32_t claim;       // queue entries a wave claims with one atomic (a multiple of 64)
     int32_t refill_below; // a traversal wave flushes finished lanes and refills when fewer lanes than this are busy
     int32_t leaf_bias;    // a primitive-test step is run when leaf lanes + bias > node lanes
+    int32_t queue_low;    // > 0: traversal defers record tests into a per-wave queue and also tests records when fewer
+                          // lanes than this have an inner node to visit; 0: the wave votes on its phase every step
     float allowed_error;  // > 0: a pixel stops accumulating within this pass once its colour error is below it
     uint32_t sample_base; // first sample index of the pass
     uint32_t strata;      // floor(sqrt(spp))
@@ -78,7 +83,8 @@ struct RenderArgs {
     uint64_t seed;
 };
 
-// d_spill must hold max(0, stack_need - LDS_STACK) * grid_blocks * BLOCK entries (stack_need = the tree's worst case).
+// d_spill must hold max(0, stack_need - LDS_STACK) * grid_blocks * BLOCK entries (stack_need = the tree's worst case;
+// SPILL_FROM instead of LDS_STACK for the render launches).
 int launch_intersect(const rtd::SceneView &scene, const RayAoS *d_rays, HitAoS *d_hits, size_t n, uint32_t *d_spill,
                      uint32_t grid_blocks, void *stream);
 // Device address and size (in 32-bit words) of the statically allocated stack-overflow buffer on the current device;

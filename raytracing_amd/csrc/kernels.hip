@@ -24,17 +24,18 @@ namespace rtk {
 // above the typical depth) spill to a per-thread column of a global buffer sized from the committed tree.
 typedef __attribute__((address_space(3))) uint32_t lds_u32; // typed LDS: accesses stay ds_read / ds_write
 
-struct LaneStack {
+template <int N> // N = entries kept in LDS
+struct LaneStackT {
     lds_u32 *col;    // &lds[thread of block]; entry e is at col[e * BLOCK]
-    uint32_t *spill; // wave-uniform base; entry LDS_STACK + e of a thread is at spill[e * threads + global thread]
+    uint32_t *spill; // wave-uniform base; entry N + e of a thread is at spill[e * threads + global thread]
     int sp;
     bool shallow; // wave-uniform: no lane of the wave is within 4 entries of the LDS part's end (see note_depth)
     __device__ __forceinline__ uint32_t *deep(int e) const {
         const size_t threads = (size_t)gridDim.x * BLOCK;
-        return spill + (size_t)(e - LDS_STACK) * threads + ((size_t)blockIdx.x * BLOCK + threadIdx.x);
+        return spill + (size_t)(e - N) * threads + ((size_t)blockIdx.x * BLOCK + threadIdx.x);
     }
     __device__ __forceinline__ void push(uint32_t v) {
-        if (shallow || sp < LDS_STACK)
+        if (shallow || sp < N)
             col[sp * BLOCK] = v;
         else
             *deep(sp) = v;
@@ -42,22 +43,25 @@ struct LaneStack {
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
-        return (shallow || sp < LDS_STACK) ? col[sp * BLOCK] : *deep(sp);
+        return (shallow || sp < N) ? col[sp * BLOCK] : *deep(sp);
     }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
     // Call with all lanes of the wave active, before a step that pushes at most three entries: the common case of a
     // shallow stack then skips the per-lane spill checks.
-    __device__ __forceinline__ void note_depth() { shallow = __ballot(sp > LDS_STACK - 4) == 0ull; }
+    __device__ __forceinline__ void note_depth() { shallow = __ballot(sp > N - 4) == 0ull; }
 };
+typedef LaneStackT<LDS_STACK> LaneStack;
 
-__device__ __forceinline__ LaneStack make_stack(uint32_t *lds, uint32_t *spill) {
-    LaneStack st;
+template <int N>
+__device__ __forceinline__ LaneStackT<N> make_stack_of(uint32_t *lds, uint32_t *spill) {
+    LaneStackT<N> st;
     st.col = (lds_u32 *)lds + threadIdx.x;
     st.spill = spill;
     st.sp = 0;
     st.shallow = false;
     return st;
 }
+__device__ __forceinline__ LaneStack make_stack(uint32_t *lds, uint32_t *spill) { return make_stack_of<LDS_STACK>(lds, spill); }
 
 // Number of set bits of a wave mask below this lane.
 __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
@@ -351,6 +355,176 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t de
         if (rank_in(~0ull) == 0u) {
             atomicAdd(reinterpret_cast<unsigned long long *>(a.visit_counters), (unsigned long long)nodes);
             atomicAdd(reinterpret_cast<unsigned long long *>(a.visit_counters) + 1, (unsigned long long)tests);
+        }
+    }
+}
+
+// extend_kernel with the record tests deferred.  A lane that reaches a leaf does not wait for the wave to run a record
+// phase: it appends (record, lane) to a queue the wave keeps in LDS and goes on with its next stack entry.  A record
+// phase takes the oldest 64 queue entries, one per lane whichever lane they came from: the tester reads the owner's
+// ray from LDS (the owner itself traverses with the reciprocals it keeps in registers), tests the record and merges its
+// candidate into the owner's best hit in LDS with a 64-bit minimum over (distance bits, primitive index) -- the order
+// closest hits are decided in anyway, so deferring changes no result.  Record phases therefore run with every lane busy and inner-node
+// steps never wait for lanes parked at a leaf; the price is that inner-node steps cull against a best distance that
+// lags behind by the queued tests (a few percent more visits).  A lane is flushed once its traversal is over and all
+// its queue entries have been tested.
+struct ExtendQueueLds {
+    uint32_t stack[QUEUE_STACK * BLOCK];
+    unsigned long long best[BLOCK]; // (bits of t) << 32 | global primitive index; t > 0, so the order is (t, index)
+    uint32_t best_slot[BLOCK];      // Closest::slot of that candidate
+    float2 ray[BLOCK][3];           // origin and direction of the lane's ray
+    uint2 queue[BLOCK / 64][QUEUE_CAP]; // per wave: x = record slot, y = owner lane
+};
+
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void extend_queue_kernel(RenderArgs a, uint32_t depth) {
+    __shared__ ExtendQueueLds lds;
+    LaneStackT<QUEUE_STACK> st = make_stack_of<QUEUE_STACK>(lds.stack, a.spill);
+    const bool primary = depth == 0u;
+    const size_t H = (size_t)SEGMENTS * a.seg_cap;
+    float *__restrict__ hits = a.hits;
+    const float *__restrict__ Q = a.payload[depth & 1u];
+    const uint32_t home = xcd_of_wave();
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave_base = tid & ~63u;
+    uint2 *queue = lds.queue[tid >> 6];
+    const unsigned long long no_hit = ((unsigned long long)__builtin_bit_cast(uint32_t, INFINITY) << 32) | RT_EMPTY;
+
+    uint32_t turn = 0, seg = home;
+    uint32_t n_in = segment_entries(a, depth, seg);
+    uint32_t c_next = 0, c_end = 0;
+    bool drained = n_in == 0u;
+
+    // wave-uniform: queue entries tested / appended so far; entry k is at queue[k % QUEUE_CAP]
+    uint32_t q_head = 0, q_tail = 0;
+    uint32_t last_post = 0; // q_tail right after this lane's latest entry: the lane has tests outstanding while q_head is below it
+
+    bool has_ray = false;
+    uint32_t slot_out = 0;
+    Trav tr;
+    tr.cur = RT_EMPTY;
+
+    for (;;) {
+        const bool live = has_ray && (tr.cur != RT_EMPTY || (int32_t)(last_post - q_head) > 0);
+        const int n_live = (int)__popcll(__ballot(live));
+        if (n_live < a.refill_below) {
+            if (has_ray && !live) {
+                const unsigned long long key = lds.best[tid];
+                const uint32_t gidx = (uint32_t)key;
+                float t = INFINITY;
+                V3 ng = mk(0.0f, 0.0f, 0.0f);
+                uint32_t code = RT_EMPTY, geom_first;
+                if (gidx != RT_EMPTY) {
+                    t = __builtin_bit_cast(float, (uint32_t)(key >> 32));
+                    const float2 r0 = lds.ray[tid][0], r1 = lds.ray[tid][1], r2 = lds.ray[tid][2];
+                    ng = candidate_normal(a.scene, lds.best_slot[tid], mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), t, code, geom_first);
+                }
+                stp(hits + 0 * H, slot_out, t);
+                stp(hits + 1 * H, slot_out, ng.x);
+                stp(hits + 2 * H, slot_out, ng.y);
+                stp(hits + 3 * H, slot_out, ng.z);
+                stp(hits + 4 * H, slot_out, __builtin_bit_cast(float, code));
+                has_ray = false;
+            }
+            while (c_next == c_end && drained && turn + 1u < (uint32_t)SEGMENTS) {
+                ++turn;
+                seg = (home + turn) & (uint32_t)(SEGMENTS - 1);
+                n_in = segment_entries(a, depth, seg);
+                drained = n_in == 0u;
+            }
+            if (c_next == c_end && !drained) {
+                uint32_t base = 0;
+                if (rank_in(~0ull) == 0u) base = atomicAdd(&a.work[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE], a.claim);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n_in) {
+                    drained = true;
+                } else {
+                    c_next = base;
+                    c_end = min(base + a.claim, n_in);
+                    if (c_end == n_in) drained = true;
+                }
+            }
+            if (c_next != c_end) {
+                const unsigned long long nmask = __ballot(!has_ray);
+                const uint32_t i = c_next + rank_in(nmask);
+                const bool take = !has_ray && i < c_end;
+                c_next = min(c_end, c_next + (uint32_t)__popcll(nmask));
+                if (take) {
+                    const uint32_t pos = seg * a.seg_cap + i;
+                    const V3 org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+                    const V3 dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
+                    if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
+                        slot_out = pos;
+                        st.sp = 0;
+                        trav_begin(a.scene, org, dir, INFINITY, tr);
+                        lds.ray[tid][0] = make_float2(org.x, org.y);
+                        lds.ray[tid][1] = make_float2(org.z, dir.x);
+                        lds.ray[tid][2] = make_float2(dir.y, dir.z);
+                        lds.best[tid] = no_hit;
+                        last_post = q_head;
+                        has_ray = true;
+                    }
+                }
+            }
+            if (__ballot(has_ray) == 0ull) {
+                if (c_next == c_end && drained && turn + 1u >= (uint32_t)SEGMENTS) break;
+                continue;
+            }
+        }
+        st.note_depth();
+        // ---- lanes at a leaf append it to the queue (while there is room) and go on with their next stack entry
+        {
+            const bool at_leaf = has_ray && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
+            const unsigned long long lmask = __ballot(at_leaf);
+            if (lmask != 0ull) {
+                const uint32_t room = (uint32_t)QUEUE_CAP - (q_tail - q_head);
+                const uint32_t r = rank_in(lmask);
+                if (at_leaf && r < room) {
+                    const uint32_t first = tr.cur & 0x0FFFFFFFu, more = (tr.cur >> 28) & 7u;
+                    queue[(q_tail + r) & (uint32_t)(QUEUE_CAP - 1)] = make_uint2(first, lane);
+                    last_post = q_tail + r + 1u;
+                    if (more != 0u)
+                        tr.cur = RT_LEAF | ((more - 1u) << 28) | (first + 1u);
+                    else
+                        tr.cur = st.empty() ? RT_EMPTY : st.pop();
+                }
+                q_tail += min((uint32_t)__popcll(lmask), room);
+            }
+        }
+        // ---- one phase: a record phase when a wave's worth of tests is waiting, the queue is about to overflow, or too
+        // few lanes have an inner node to visit; an inner-node step otherwise
+        const bool at_leaf = has_ray && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
+        const bool at_node = has_ray && tr.cur != RT_EMPTY && !at_leaf;
+        const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+        const uint32_t q_len = q_tail - q_head;
+        const bool record_phase = q_len >= 64u || q_len + n_leaf > (uint32_t)QUEUE_CAP || (n_node == 0u && n_leaf == 0u && q_len > 0u) ||
+                                  (n_node < q_len && n_node < (uint32_t)a.queue_low);
+        if (!record_phase) {
+            if (at_node) {
+                tr.best.t = __builtin_bit_cast(float, reinterpret_cast<const uint32_t *>(&lds.best[tid])[1]);
+                trav_node_step(a.scene, RT_TNEAR, tr, st);
+            }
+        } else {
+            const uint32_t take = min(q_len, 64u);
+            const bool mine = lane < take;
+            if (mine) {
+                const uint2 e = queue[(q_head + lane) & (uint32_t)(QUEUE_CAP - 1)];
+                const uint32_t owner = wave_base + e.y;
+                const float2 r0 = lds.ray[owner][0], r1 = lds.ray[owner][1], r2 = lds.ray[owner][2];
+                const V3 o = mk(r0.x, r0.y, r1.x), d = mk(r1.y, r2.x, r2.y);
+                Closest c;
+                c.t = INFINITY;
+                c.gidx = RT_EMPTY;
+                c.slot = 0;
+                c.u = c.v = 0.0f;
+                test_prim(a.scene, e.x, o, d, RT_TNEAR, c);
+                if (c.gidx != RT_EMPTY) {
+                    const unsigned long long key = ((unsigned long long)__builtin_bit_cast(uint32_t, c.t) << 32) | c.gidx;
+                    atomicMin(&lds.best[owner], key);
+                    // the lane whose candidate is the owner's best after every lane's minimum records where it came from
+                    if (lds.best[owner] == key) lds.best_slot[owner] = c.slot;
+                }
+            }
+            q_head += take;
         }
     }
 }
@@ -705,7 +879,10 @@ int launch_intersect(const SceneView &scene, const RayAoS *d_rays, HitAoS *d_hit
 
 int launch_extend(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(extend_kernel, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
+    if (args.queue_low > 0 && args.visit_counters == nullptr) // visits are counted on the undeferred traversal
+        hipLaunchKernelGGL(extend_queue_kernel, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
+    else
+        hipLaunchKernelGGL(extend_kernel, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth);
     return check_launch();
 }
 
@@ -734,9 +911,10 @@ int launch_raygen(const RenderArgs &args, void *stream) {
 }
 
 int extend_blocks_per_cu() {
-    int n = 0;
+    int n = 0, m = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, extend_kernel, BLOCK, 0) != hipSuccess || n < 1) n = 1;
-    return n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, extend_queue_kernel, BLOCK, 0) != hipSuccess || m < 1) m = 1;
+    return n > m ? n : m; // the grid of either kernel: more blocks than fit just wait their turn
 }
 
 int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, void *stream) {

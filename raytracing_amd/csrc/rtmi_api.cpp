@@ -376,7 +376,7 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
     // resident grid of the traversal kernel (its LDS stack and registers bound the blocks per CU)
     {
         scene->grid_blocks = (uint32_t)dev->n_cu * (uint32_t)rtk::extend_blocks_per_cu();
-        const size_t deep = bvh.stack_need > (uint32_t)rtk::LDS_STACK ? bvh.stack_need - rtk::LDS_STACK : 0;
+        const size_t deep = bvh.stack_need > (uint32_t)rtk::SPILL_FROM ? bvh.stack_need - rtk::SPILL_FROM : 0;
         scene->spill_bytes = std::max<size_t>(16, deep * scene->grid_blocks * rtk::BLOCK * sizeof(uint32_t));
         HIP_TRY(hipMalloc((void **)&scene->d_spill, scene->spill_bytes));
     }
@@ -822,6 +822,8 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.leaf_bias = 0;
     if (const char *v = getenv("RTMI_REFILL_BELOW")) a.refill_below = atoi(v);
     if (const char *v = getenv("RTMI_LEAF_BIAS")) a.leaf_bias = atoi(v);
+    a.queue_low = 0;
+    if (const char *v = getenv("RTMI_QUEUE_LOW")) a.queue_low = std::max(0, std::min(64, atoi(v)));
     a.refill_below = std::max(1, std::min(64, a.refill_below)); // below 1 a drained wave would never flush
     a.spill = scene->d_spill;
     const uint32_t full_grid = scene->grid_blocks;

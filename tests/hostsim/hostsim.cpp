@@ -18,11 +18,14 @@ using namespace rtd;
 
 namespace {
 
+unsigned long long g_push_hist[64]; // pushes by stack position, for sizing the LDS part of the kernels' stack
+
 struct VecStack {
     uint32_t data[256];
     int sp = 0;
     int high = 0;
     void push(uint32_t v) {
+        ++g_push_hist[sp < 63 ? sp : 63];
         data[sp++] = v;
         if (sp > high) high = sp;
     }
@@ -58,6 +61,13 @@ struct Params {
 } // namespace
 
 extern "C" {
+
+// pushes counted by stack position since the last call with reset != 0
+void hs_push_hist(unsigned long long out[64], int reset) {
+    for (int k = 0; k < 64; ++k) out[k] = g_push_hist[k];
+    if (reset)
+        for (int k = 0; k < 64; ++k) g_push_hist[k] = 0;
+}
 
 void *hs_scene_new() {
     Scene *s = new Scene();
@@ -656,6 +666,125 @@ extern "C" void hs_block_sim(void *p, const Ray *rays, size_t n, int refill_belo
                 out[node_phase ? 2 : 3] += active;
                 out[node_phase ? 4 : 5] += 1.0;
                 out[7] += swapped ? 1.0 : 0.0;
+            }
+        }
+    }
+}
+
+// Model of a wave that defers its record tests into a queue shared by its 64 lanes: a lane that reaches a leaf appends
+// (lane, record) to the queue and goes on with its next stack entry; a record phase takes up to 64 queue entries, one
+// per lane whatever lane the entry came from (ray and best candidate are read from / merged into the owner's state, as
+// they would be through LDS), so a record phase runs with every lane busy whenever 64 entries are waiting.  A lane
+// with no node left is flushed only once all its entries have been tested.  Candidates are merged by (t, primitive
+// index), so the deferred order does not change the result; what changes is that inner-node steps see a best distance
+// that lags behind (less culling), which the model reproduces because it runs the real traversal.
+// cost = {node step, record step, refill pass, per iteration, post pass}; fire = queue length that triggers a record
+// phase; cap = queue capacity; a record phase also runs when fewer than `low` lanes have a node and the queue holds
+// more entries than that.  out as hs_wave_sim; out[7] = record phases with fewer than 64 entries.
+extern "C" void hs_queue_sim(void *p, const Ray *rays, size_t n, int refill_below, int fire, int cap, int low,
+                             const double cost[5], double out[8]) {
+    Scene *s = (Scene *)p;
+    const double c_node = cost[0], c_leaf = cost[1], c_refill = cost[2], c_iter = cost[3], c_post = cost[4];
+    struct Lane {
+        bool has = false;
+        V3 o, d;
+        Trav tr;
+        VecStack st;
+        uint64_t last_post = 0; // sequence number after this lane's latest entry
+    };
+    struct Entry {
+        int lane;
+        uint32_t slot;
+    };
+    for (int k = 0; k < 8; ++k) out[k] = 0.0;
+    size_t next = 0;
+    while (next < n) {
+        const size_t wave_end = std::min(n, next + 4096);
+        std::vector<Lane> L(64);
+        std::vector<Entry> q;
+        uint64_t q_done = 0, q_posted = 0;
+        size_t q_head = 0;
+        auto pending = [&](const Lane &l) { return l.last_post > q_done; };
+        for (;;) {
+            int n_live = 0;
+            for (auto &l : L)
+                if (l.has && (l.tr.cur != RT_EMPTY || pending(l))) ++n_live;
+            if (n_live < refill_below || n_live == 0) {
+                bool any = false;
+                for (auto &l : L) {
+                    if (l.has && l.tr.cur == RT_EMPTY && !pending(l)) l.has = false, any = true;
+                    if (!l.has && next < wave_end) {
+                        const Ray &r = rays[next++];
+                        l.o = mk(r.org[0], r.org[1], r.org[2]);
+                        l.d = mk(r.dir[0], r.dir[1], r.dir[2]);
+                        l.st = VecStack();
+                        trav_begin(s->view, l.o, l.d, INFINITY, l.tr);
+                        l.last_post = 0;
+                        l.has = true;
+                        any = true;
+                    }
+                }
+                if (any) out[0] += 64.0 * c_refill, out[6] += 1.0;
+                n_live = 0;
+                for (auto &l : L)
+                    if (l.has && (l.tr.cur != RT_EMPTY || pending(l))) ++n_live;
+                if (n_live == 0) {
+                    if (next >= wave_end) break;
+                    continue;
+                }
+            }
+            out[0] += 64.0 * c_iter;
+            // post pass: every lane at a leaf appends one record (while the queue has room) and pops
+            bool posted = false;
+            for (int i = 0; i < 64; ++i) {
+                Lane &l = L[i];
+                if (!(l.has && l.tr.cur != RT_EMPTY && (l.tr.cur & RT_LEAF))) continue;
+                if ((int)(q.size() - q_head) >= cap) break;
+                const uint32_t first = l.tr.cur & 0x0FFFFFFFu, more = (l.tr.cur >> 28) & 7u;
+                q.push_back({i, first});
+                l.last_post = ++q_posted;
+                posted = true;
+                if (more != 0u)
+                    l.tr.cur = RT_LEAF | ((more - 1u) << 28) | (first + 1u);
+                else
+                    l.tr.cur = l.st.empty() ? RT_EMPTY : l.st.pop();
+            }
+            if (posted) out[0] += 64.0 * c_post;
+            int n_node = 0, n_leaf = 0;
+            for (auto &l : L) {
+                if (!l.has || l.tr.cur == RT_EMPTY) continue;
+                if (l.tr.cur & RT_LEAF)
+                    ++n_leaf; // posts in the next iteration
+                else
+                    ++n_node;
+            }
+            const int q_len = (int)(q.size() - q_head);
+            const bool full = q_len + n_leaf > cap;
+            const bool record_phase = q_len >= fire || full || (n_node == 0 && n_leaf == 0 && q_len > 0) || (n_node < q_len && n_node < low);
+            if (!record_phase) {
+                if (n_node == 0) continue; // lanes at leaves post in the next iteration
+                out[0] += 64.0 * c_node;
+                out[4] += 1.0;
+                for (auto &l : L)
+                    if (l.has && l.tr.cur != RT_EMPTY && !(l.tr.cur & RT_LEAF)) {
+                        trav_node_step(s->view, RT_TNEAR, l.tr, l.st);
+                        out[1] += c_node;
+                        out[2] += 1.0;
+                    }
+            } else {
+                const int take = std::min(q_len, 64);
+                out[0] += 64.0 * c_leaf;
+                out[5] += 1.0;
+                if (take < 64) out[7] += 1.0;
+                for (int k = 0; k < take; ++k) {
+                    const Entry e = q[q_head++];
+                    Lane &l = L[e.lane];
+                    test_prim(s->view, e.slot, l.o, l.d, RT_TNEAR, l.tr.best);
+                    out[1] += c_leaf;
+                    out[3] += 1.0;
+                }
+                q_done += (uint64_t)take;
+                if (q_head == q.size()) q.clear(), q_head = 0;
             }
         }
     }
