@@ -325,8 +325,9 @@ def main():
         steps = max(args.steps, 1)
         ms_per_step = elapsed / steps * 1e3
         value = total_rays / elapsed / 1e6
-        # roofline of the dominant kernel (extend_kernel: BVH traversal + primitive tests of every ray of a bounce),
-        # from this rank's own launches: HIP events around every launch give its time, a separate untimed render
+        # roofline of the dominant kernel (the traversal launches, one per bounce: BVH traversal + primitive tests of
+        # every ray of the bounce; extend_queue_kernel on the first two bounces, extend_kernel on the rest, the same
+        # work scheduled in two ways), from this rank's own launches: HIP events around every launch give its time, a separate untimed render
         # with the visit counters on gives the node and record fetches
         roofline = None
         if not args.no_visits:
@@ -363,9 +364,11 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "extend_kernel",
-                "limited_by": "VALU issue at partial lane utilisation and gather latency (SQ counters in profiles/); "
-                              "priced against HBM peak because its algorithmic work is bytes gathered, not flops",
+                "kernel": "extend_kernel + extend_queue_kernel (the traversal launch of every bounce)",
+                "limited_by": "bounces 0-1: VALU issue at partial lane utilisation; deeper bounces: the rate at which "
+                              "the memory system returns scattered 128-byte lines (TA busy 0.9-0.99, SQ / TCP / TCC "
+                              "counters in profiles/); priced against HBM peak because the algorithmic work is bytes "
+                              "gathered, not flops",
                 "launches_per_step": n_launch,
                 "avg_launch_ms": extend_ms / max(launches, 1),
                 "kernel_ms_per_step": extend_ms / steps,

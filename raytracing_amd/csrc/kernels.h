@@ -20,7 +20,7 @@ constexpr int PIXEL_BLOCK = 64;     // pixels whose samples are adjacent in path
 constexpr int SEGMENTS = 8;         // queue segments, one per XCD (each XCD has its own L2)
 constexpr int COUNTER_STRIDE = 64;  // uint32 slots between two counters: every counter has a 256-byte line to itself
 constexpr int LDS_STACK = 24;       // stack entries kept in LDS per lane; deeper entries spill to global memory
-constexpr int QUEUE_STACK = 13;     // the same in the traversal kernel that defers its record tests (LDS also holds its queue)
+constexpr int QUEUE_STACK = 14;     // the same in the traversal kernel that defers its record tests (LDS also holds its queue)
 constexpr int QUEUE_CAP = 128;      // record tests a wave of that kernel can have waiting (a power of two)
 constexpr int SPILL_FROM = QUEUE_STACK < LDS_STACK ? QUEUE_STACK : LDS_STACK; // first stack entry that may spill
 

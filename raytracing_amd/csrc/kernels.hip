@@ -30,9 +30,11 @@ struct LaneStackT {
     uint32_t *spill; // wave-uniform base; entry N + e of a thread is at spill[e * threads + global thread]
     int sp;
     bool shallow; // wave-uniform: no lane of the wave is within 4 entries of the LDS part's end (see note_depth)
+    // uniform base + 32-bit byte offset (the overflow buffer stays below 4 GiB: MAX_STACK entries of a resident grid)
     __device__ __forceinline__ uint32_t *deep(int e) const {
-        const size_t threads = (size_t)gridDim.x * BLOCK;
-        return spill + (size_t)(e - N) * threads + ((size_t)blockIdx.x * BLOCK + threadIdx.x);
+        const uint32_t threads = gridDim.x * (uint32_t)BLOCK;
+        const uint32_t off = ((uint32_t)(e - N) * threads + (blockIdx.x * (uint32_t)BLOCK + threadIdx.x)) << 2;
+        return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(spill) + off);
     }
     __device__ __forceinline__ void push(uint32_t v) {
         if (shallow || sp < N)
@@ -373,8 +375,10 @@ struct ExtendQueueLds {
     unsigned long long best[BLOCK]; // (bits of t) << 32 | global primitive index; t > 0, so the order is (t, index)
     uint32_t best_slot[BLOCK];      // Closest::slot of that candidate
     float2 ray[BLOCK][3];           // origin and direction of the lane's ray
-    uint2 queue[BLOCK / 64][QUEUE_CAP]; // per wave: x = record slot, y = owner lane
+    uint32_t slot_out[BLOCK];       // where the lane's hit record goes
+    uint32_t queue[BLOCK / 64][QUEUE_CAP]; // per wave: owner lane << 26 | record slot (a scene has fewer than 2^26 records)
 };
+static_assert(RT_MAX_ITEMS <= (1u << 26), "a queue entry keeps the record slot in 26 bits");
 
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void extend_queue_kernel(RenderArgs a, uint32_t depth) {
     __shared__ ExtendQueueLds lds;
@@ -384,8 +388,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
     float *__restrict__ hits = a.hits;
     const float *__restrict__ Q = a.payload[depth & 1u];
     const uint32_t home = xcd_of_wave();
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave_base = tid & ~63u;
-    uint2 *queue = lds.queue[tid >> 6];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u); // wave-uniform, kept in a scalar register
+    uint32_t *queue = lds.queue[wave_base >> 6];
     const unsigned long long no_hit = ((unsigned long long)__builtin_bit_cast(uint32_t, INFINITY) << 32) | RT_EMPTY;
 
     uint32_t turn = 0, seg = home;
@@ -398,7 +403,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
     uint32_t last_post = 0; // q_tail right after this lane's latest entry: the lane has tests outstanding while q_head is below it
 
     bool has_ray = false;
-    uint32_t slot_out = 0;
     Trav tr;
     tr.cur = RT_EMPTY;
 
@@ -417,6 +421,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
                     const float2 r0 = lds.ray[tid][0], r1 = lds.ray[tid][1], r2 = lds.ray[tid][2];
                     ng = candidate_normal(a.scene, lds.best_slot[tid], mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), t, code, geom_first);
                 }
+                const uint32_t slot_out = lds.slot_out[tid];
                 stp(hits + 0 * H, slot_out, t);
                 stp(hits + 1 * H, slot_out, ng.x);
                 stp(hits + 2 * H, slot_out, ng.y);
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
                     const V3 org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
                     const V3 dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
                     if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
-                        slot_out = pos;
+                        lds.slot_out[tid] = pos;
                         st.sp = 0;
                         trav_begin(a.scene, org, dir, INFINITY, tr);
                         lds.ray[tid][0] = make_float2(org.x, org.y);
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
                 const uint32_t r = rank_in(lmask);
                 if (at_leaf && r < room) {
                     const uint32_t first = tr.cur & 0x0FFFFFFFu, more = (tr.cur >> 28) & 7u;
-                    queue[(q_tail + r) & (uint32_t)(QUEUE_CAP - 1)] = make_uint2(first, lane);
+                    queue[(q_tail + r) & (uint32_t)(QUEUE_CAP - 1)] = (lane << 26) | first;
                     last_post = q_tail + r + 1u;
                     if (more != 0u)
                         tr.cur = RT_LEAF | ((more - 1u) << 28) | (first + 1u);
@@ -501,14 +506,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
         if (!record_phase) {
             if (at_node) {
                 tr.best.t = __builtin_bit_cast(float, reinterpret_cast<const uint32_t *>(&lds.best[tid])[1]);
+                // -origin / direction from the origin in LDS (the same operations trav_begin does): three registers
+                // fewer to carry through the record phases
+                const float2 r0 = lds.ray[tid][0], r1 = lds.ray[tid][1];
+                tr.nox = -(r0.x * tr.ix);
+                tr.noy = -(r0.y * tr.iy);
+                tr.noz = -(r1.x * tr.iz);
                 trav_node_step(a.scene, RT_TNEAR, tr, st);
             }
         } else {
             const uint32_t take = min(q_len, 64u);
             const bool mine = lane < take;
             if (mine) {
-                const uint2 e = queue[(q_head + lane) & (uint32_t)(QUEUE_CAP - 1)];
-                const uint32_t owner = wave_base + e.y;
+                const uint32_t e = queue[(q_head + lane) & (uint32_t)(QUEUE_CAP - 1)];
+                const uint32_t owner = wave_base + (e >> 26);
                 const float2 r0 = lds.ray[owner][0], r1 = lds.ray[owner][1], r2 = lds.ray[owner][2];
                 const V3 o = mk(r0.x, r0.y, r1.x), d = mk(r1.y, r2.x, r2.y);
                 Closest c;
@@ -516,7 +527,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
                 c.gidx = RT_EMPTY;
                 c.slot = 0;
                 c.u = c.v = 0.0f;
-                test_prim(a.scene, e.x, o, d, RT_TNEAR, c);
+                test_prim(a.scene, e & 0x03FFFFFFu, o, d, RT_TNEAR, c);
                 if (c.gidx != RT_EMPTY) {
                     const unsigned long long key = ((unsigned long long)__builtin_bit_cast(uint32_t, c.t) << 32) | c.gidx;
                     atomicMin(&lds.best[owner], key);

@@ -822,8 +822,13 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.leaf_bias = 0;
     if (const char *v = getenv("RTMI_REFILL_BELOW")) a.refill_below = atoi(v);
     if (const char *v = getenv("RTMI_LEAF_BIAS")) a.leaf_bias = atoi(v);
+    // the first bounces (rays that still share the top of the tree in L2) are bound by instruction issue and gain from
+    // deferring the record tests; deeper bounces are bound by the gathers and lose, so they keep the voting kernel
+    int queue_low = 16;
+    uint32_t queue_depths = 2;
+    if (const char *v = getenv("RTMI_QUEUE_LOW")) queue_low = std::max(0, std::min(64, atoi(v)));
+    if (const char *v = getenv("RTMI_QUEUE_DEPTHS")) queue_depths = (uint32_t)std::max(0, atoi(v));
     a.queue_low = 0;
-    if (const char *v = getenv("RTMI_QUEUE_LOW")) a.queue_low = std::max(0, std::min(64, atoi(v)));
     a.refill_below = std::max(1, std::min(64, a.refill_below)); // below 1 a drained wave would never flush
     a.spill = scene->d_spill;
     const uint32_t full_grid = scene->grid_blocks;
@@ -893,6 +898,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             a.claim = 64u * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, per_wave / 64));
             // timed on its own: the traversal launch is what the roofline of the dominant kernel needs
             const int t_extend = watch.start(stream, &extend_ms);
+            a.queue_low = depth < queue_depths ? queue_low : 0;
             int lrc = rtk::launch_extend(a, depth, grid, stream);
             watch.stop(t_extend, stream);
             if (lrc || rtk::launch_shade(a, depth, longest, stream)) {

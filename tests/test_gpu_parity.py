@@ -162,6 +162,23 @@ def test_accumulators_bit_equal_to_oracle(oracle, scene_classes, device, monkeyp
     assert eq.all(), "%d of %d accumulator words differ" % ((~eq).sum(), eq.size)
 
 
+@pytest.mark.parametrize("name,size,spp,kw", [("cornell-box", (160, 90), 5, {}), ("dragon", (128, 72), 6, {"levels": 2}),
+                                              ("spheres", (160, 90), 9, {})])
+@pytest.mark.parametrize("queue_depths", ["0", "99"])
+def test_both_traversal_kernels_bit_equal_to_oracle(oracle, scene_classes, device, monkeypatch, name, size, spp, kw,
+                                                    queue_depths):
+    """The library traces the first bounces with the kernel that defers record tests into a per-wave queue and the rest
+    with the kernel that votes on its phase; RTMI_QUEUE_DEPTHS moves the switch.  Here every bounce runs in one of them
+    (no tail kernel), and both must give the oracle's accumulators."""
+    monkeypatch.setenv("RTMI_TAIL_RAYS", "0")
+    monkeypatch.setenv("RTMI_QUEUE_DEPTHS", queue_depths)
+    so, world = build_pair(oracle, scene_classes[name], device, **kw)
+    got, st, want, want_rays = render_both(oracle, so, world, device, size[0], size[1], spp)
+    assert st["rays"] == want_rays and st["tail_rays"] == 0
+    eq = same_bits(got, want)
+    assert eq.all(), "%d of %d accumulator words differ" % ((~eq).sum(), eq.size)
+
+
 @pytest.mark.parametrize("tail", ["kernels per bounce", "tail kernel", "tail kernel late"])
 @pytest.mark.parametrize("aperture", [0.0, 0.1])
 def test_thin_and_smooth_dielectrics_and_thin_lens_camera(oracle, device, monkeypatch, tail, aperture):
@@ -428,12 +445,14 @@ def test_deep_traversal_stack_spills(oracle, device):
     check_hits(world.intersect(rays), so.intersect(rays, oracle.ISECT_BRUTE))
 
 
-@pytest.mark.parametrize("tail_rays", ["0", "1000000"])
-def test_deep_traversal_stack_in_render(oracle, device, monkeypatch, tail_rays):
-    """The same kind of soup, diffuse, rendered from inside: the spill path of the per-bounce traversal kernel
-    (RTMI_TAIL_RAYS=0) and of the tail kernel, against the oracle's accumulators."""
+@pytest.mark.parametrize("tail_rays,queue_depths", [("0", "0"), ("0", "99"), ("1000000", "2")])
+def test_deep_traversal_stack_in_render(oracle, device, monkeypatch, tail_rays, queue_depths):
+    """The same kind of soup, diffuse, rendered from inside: the spill path of both per-bounce traversal kernels
+    (RTMI_TAIL_RAYS=0; the one that queues its record tests keeps fewer stack entries in LDS) and of the tail kernel,
+    against the oracle's accumulators."""
     from raytracing_amd import api, types
     monkeypatch.setenv("RTMI_TAIL_RAYS", tail_rays)
+    monkeypatch.setenv("RTMI_QUEUE_DEPTHS", queue_depths)
     rng = np.random.default_rng(6)
     n = 30000
     c = rng.uniform(-1, 1, (n, 3)) + np.array([0, 0, -2.5])
