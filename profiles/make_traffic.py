@@ -50,7 +50,7 @@ for k in sorted(fetch):
         "write_size_kib": write.get(k, 0.0),
         "hbm_bytes_per_frame": (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0,
     }
-ext = [k for k in summary if "extend_kernel" in k]
+ext = [k for k in summary if "extend_kernel" in k or "extend_queue_kernel" in k]  # the traversal launch of every bounce
 launches = sum(summary[k]["launches_per_frame"] for k in ext)
 total = sum(summary[k]["hbm_bytes_per_frame"] for k in ext)
 stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
@@ -60,7 +60,7 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, on
            "workload": key, "kernels": summary}, open(os.path.join(here, name + "_traffic_summary.json"), "w"), indent=1)
 tfile = os.path.join(here, "traffic.json")
 tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
-tj[key] = {"kernel": "extend_kernel", "launches": launches, "hbm_bytes_per_launch": total / max(launches, 1),
+tj[key] = {"kernel": "extend_kernel + extend_queue_kernel", "launches": launches, "hbm_bytes_per_launch": total / max(launches, 1),
            "hbm_bytes_per_frame": total, "from": name + "_traffic_summary.json"}
 json.dump(tj, open(tfile, "w"), indent=1)
 print(json.dumps(tj[key]))
