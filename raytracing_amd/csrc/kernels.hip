@@ -597,15 +597,19 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
             bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, a.pixels[2 * e.pix], a.pixels[2 * e.pix + 1], e.sample,
                                      depth, org, dir, beta, vo);
             if (depth == 0u) {
-                stp(S + 3 * P, pid, vo.normal.x);
-                stp(S + 4 * P, pid, vo.normal.y);
-                stp(S + 5 * P, pid, vo.normal.z);
-                stp(S + 6 * P, pid, vo.position.x);
-                stp(S + 7 * P, pid, vo.position.y);
-                stp(S + 8 * P, pid, vo.position.z);
-                stp(S + 9 * P, pid, vo.albedo.x);
-                stp(S + 10 * P, pid, vo.albedo.y);
-                stp(S + 11 * P, pid, vo.albedo.z);
+                // a camera ray that leaves the scene has all-zero first-hit outputs: only z (0 = no hit, a hit has
+                // z = t > 0) is stored for it, and accumulate_kernel reads the other nine planes for hits only
+                if (h.hit) {
+                    stp(S + 3 * P, pid, vo.normal.x);
+                    stp(S + 4 * P, pid, vo.normal.y);
+                    stp(S + 5 * P, pid, vo.normal.z);
+                    stp(S + 6 * P, pid, vo.position.x);
+                    stp(S + 7 * P, pid, vo.position.y);
+                    stp(S + 8 * P, pid, vo.position.z);
+                    stp(S + 9 * P, pid, vo.albedo.x);
+                    stp(S + 10 * P, pid, vo.albedo.y);
+                    stp(S + 11 * P, pid, vo.albedo.z);
+                }
                 stp(S + 12 * P, pid, vo.z);
                 ray_depth = 0.0f + vo.t_add;
             } else if (h.hit && vo.t_add != 0.0f) {
@@ -777,9 +781,14 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *
                 acc[6 + ch] = acc[6 + ch] + w * col[ch];
             }
             acc[9] += w;
+            // first-hit outputs of a camera ray that hit nothing are zeros that were never stored (z == 0 marks
+            // them); the sums never hold -0, so leaving out the addition of +0 changes no bit
+            const float z = S[12 * P + pid];
+            if (z != 0.0f) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc[10 + k] = acc[10 + k] + S[(size_t)(3 + k) * P + pid];
-            acc[19] += S[12 * P + pid];
+                for (int k = 0; k < 9; ++k) acc[10 + k] = acc[10 + k] + S[(size_t)(3 + k) * P + pid];
+            }
+            acc[19] += z;
             acc[20] += S[13 * P + pid];
             acc[21] += count_inc;
             // crates/rt-cli/src/executor.rs:244-249: the pixel is done for this batch once all channels are precise
