@@ -79,11 +79,11 @@ struct Stopwatch {
                 iv.closed = true;
             }
     }
-    // Only valid right after a synchronisation with the stream: every closed interval has finished.
+    // Adds up and recycles the closed intervals whose end has been reached on the device.
     void collect() {
         std::vector<Interval> open;
         for (const Interval &iv : pending) {
-            if (!iv.closed) {
+            if (!iv.closed || hipEventQuery(iv.end) != hipSuccess) {
                 open.push_back(iv);
                 continue;
             }
@@ -789,7 +789,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     uint32_t *d_work = film->d_counts + film->cap_counters;
     // only the counters of the bounces this call can reach are zeroed per pass
     const size_t used_counters = n_counters;
-    std::vector<uint32_t> h_counts(per_bounce), h_all;
+    std::vector<uint32_t> h_all;
 
     rtk::RenderArgs a{};
     a.scene = scene->view;
@@ -833,6 +833,14 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.spill = scene->d_spill;
     const uint32_t full_grid = scene->grid_blocks;
 
+    if (!dev->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&dev->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc((void **)&dev->h_counts, rtmi_device::COUNT_RING * per_bounce * sizeof(uint32_t), hipHostMallocDefault));
+        for (int r = 0; r < rtmi_device::COUNT_RING; ++r) {
+            HIP_TRY(hipEventCreateWithFlags(&dev->ev_shaded[r], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&dev->ev_copied[r], hipEventDisableTiming));
+        }
+    }
     Stopwatch watch;
     float total_ms = 0.0f, bounce_ms = 0.0f, extend_ms = 0.0f;
     const int t_total = watch.start(stream, &total_ms);
@@ -873,16 +881,41 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             rc = fail(RTMI_ERR_DEVICE, "raygen kernel launch failed");
             break;
         }
-        // `live` / `longest`: rays entering the bounce about to be launched and the entries of its longest segment,
-        // from the survivor counters read back after every bounce.  Once fewer than tail_rays are left a launch per
-        // bounce costs more than the bounce, and one tail_kernel launch runs the remaining paths to their end.
+        // `live` / `longest`: rays entering a bounce and the entries of its longest segment.  For bounce 0 they are
+        // known; from then on they are the survivor counters the shade kernel leaves, copied to the host on the copy
+        // stream while the render stream goes on.  The host stays one bounce ahead of the device: bounce d is launched
+        // with the counts of bounce d - 1 as upper bounds (survivors never outnumber the rays they come from; the
+        // kernels read the exact counts on the device), so no bounce waits for the host.  Once fewer than tail_rays
+        // are left a launch per bounce costs more than the bounce, and one tail_kernel launch runs the remaining
+        // paths to their end.
         uint64_t live = (uint64_t)k * (npix - n_done);
         uint32_t longest = a.seg_cap;
         uint32_t launched = 0, tail_from = 0; // bounces whose counters are valid; first bounce of the tail (0 = none)
         paths += live;
         const uint64_t camera_rays = live;
+        uint64_t expected = live; // rays expected to enter the bounce: the bound scaled by the last bounce's survival rate
         for (uint32_t depth = 0; depth < params->max_depth && live > 0; ++depth) {
-            if (depth > 0 && live < tail_rays &&
+            if (depth >= 2) {
+                const uint64_t before = live;
+                // exact input of bounce depth - 1 (copied after bounce depth - 2 was shaded): the bound for this bounce
+                const int slot = (int)((depth - 1) % rtmi_device::COUNT_RING);
+                hipError_t ce = hipEventSynchronize(dev->ev_copied[slot]);
+                if (ce != hipSuccess) {
+                    rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(ce));
+                    break;
+                }
+                watch.collect();
+                const uint32_t *hc = dev->h_counts + (size_t)slot * per_bounce;
+                live = 0;
+                longest = 0;
+                for (int x = 0; x < rtk::SEGMENTS; ++x) {
+                    live += hc[(size_t)x * rtk::COUNTER_STRIDE];
+                    longest = std::max(longest, hc[(size_t)x * rtk::COUNTER_STRIDE]);
+                }
+                if (live == 0) break; // bounce depth - 1 already ran on an empty queue
+                expected = (uint64_t)((double)live * (double)live / (double)std::max<uint64_t>(before, 1));
+            }
+            if (depth > 0 && expected < tail_rays &&
                 (uint64_t)((longest + rtk::BLOCK - 1) / rtk::BLOCK) * rtk::SEGMENTS <= full_grid) {
                 if (rtk::launch_tail(a, depth, longest, stream)) rc = fail(RTMI_ERR_DEVICE, "tail kernel launch failed");
                 tail_from = depth;
@@ -908,19 +941,28 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             ++launches;
             ++launched;
             if (depth + 1 == params->max_depth) break;
-            // the survivors' count sizes (or ends) the next launch
-            if ((rc = read_back(h_counts.data(), d_counts + (size_t)(depth + 1) * per_bounce,
-                                per_bounce * sizeof(uint32_t))) != RTMI_OK)
-                break;
-            live = 0;
-            longest = 0;
-            for (int x = 0; x < rtk::SEGMENTS; ++x) {
-                live += h_counts[(size_t)x * rtk::COUNTER_STRIDE];
-                longest = std::max(longest, h_counts[(size_t)x * rtk::COUNTER_STRIDE]);
+            // the survivors' counters, to the host behind the render stream's back
+            {
+                const int slot = (int)((depth + 1) % rtmi_device::COUNT_RING);
+                hipError_t ce = hipEventRecord(dev->ev_shaded[slot], stream);
+                if (ce == hipSuccess) ce = hipStreamWaitEvent(dev->copy_stream, dev->ev_shaded[slot], 0);
+                if (ce == hipSuccess)
+                    ce = hipMemcpyAsync(dev->h_counts + (size_t)slot * per_bounce, d_counts + (size_t)(depth + 1) * per_bounce,
+                                        per_bounce * sizeof(uint32_t), hipMemcpyDeviceToHost, dev->copy_stream);
+                if (ce == hipSuccess) ce = hipEventRecord(dev->ev_copied[slot], dev->copy_stream);
+                if (ce != hipSuccess) {
+                    rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(ce));
+                    break;
+                }
             }
         }
         if (rc != RTMI_OK) break;
         watch.stop(t_pass, stream);
+        // queued before the host reads the pass's counters, so that the device does not wait for that read
+        if (rtk::launch_accumulate(a, film->d_accum, 1.0f, stream)) {
+            rc = fail(RTMI_ERR_DEVICE, "accumulate kernel launch failed");
+            break;
+        }
         // exact ray count and deepest bounce of the pass from the counters of every bounce that ran (read in chunks
         // of 256 bounces up to the first empty one: live counts never grow from one bounce to the next)
         rays += camera_rays;
@@ -945,10 +987,6 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             }
         }
         if (rc != RTMI_OK) break;
-        if (rtk::launch_accumulate(a, film->d_accum, 1.0f, stream)) {
-            rc = fail(RTMI_ERR_DEVICE, "accumulate kernel launch failed");
-            break;
-        }
         if (use_done && pass + 1 < n_passes) rc = read_back(&n_done, film->d_done + npix, sizeof(uint32_t));
         sample += k;
     }

@@ -66,6 +66,13 @@ struct rtmi_device {
     int n_cu = 256;
     uint32_t *static_spill = nullptr; // this device's copy of the statically allocated stack-overflow buffer
     size_t static_spill_words = 0;
+    // Survivor counters come back to the host on a stream of their own, so that the copy is not between two bounces on
+    // the render stream: ring of pinned slots, "bounce shaded" / "counters copied" event pairs (created on first use).
+    static constexpr int COUNT_RING = 4;
+    hipStream_t copy_stream = nullptr;
+    uint32_t *h_counts = nullptr; // COUNT_RING slots of SEGMENTS * COUNTER_STRIDE words, pinned
+    hipEvent_t ev_shaded[COUNT_RING] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_copied[COUNT_RING] = {nullptr, nullptr, nullptr, nullptr};
     std::atomic<int> refs{1}; // the handle itself + one per scene and film created on it
 };
 
@@ -79,6 +86,15 @@ inline void rtmi_device_release(rtmi_device *dev) {
         (void)hipStreamDestroy(dev->stream);
     }
     if (dev->d_visits) (void)hipFree(dev->d_visits);
+    if (dev->copy_stream) {
+        (void)hipStreamSynchronize(dev->copy_stream);
+        (void)hipStreamDestroy(dev->copy_stream);
+    }
+    if (dev->h_counts) (void)hipHostFree(dev->h_counts);
+    for (int k = 0; k < rtmi_device::COUNT_RING; ++k) {
+        if (dev->ev_shaded[k]) (void)hipEventDestroy(dev->ev_shaded[k]);
+        if (dev->ev_copied[k]) (void)hipEventDestroy(dev->ev_copied[k]);
+    }
     delete dev;
 }
 
