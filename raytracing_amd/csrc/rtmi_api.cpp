@@ -833,13 +833,15 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.spill = scene->d_spill;
     const uint32_t full_grid = scene->grid_blocks;
 
-    if (!dev->copy_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&dev->copy_stream, hipStreamNonBlocking));
-        HIP_TRY(hipHostMalloc((void **)&dev->h_counts, rtmi_device::COUNT_RING * per_bounce * sizeof(uint32_t), hipHostMallocDefault));
-        for (int r = 0; r < rtmi_device::COUNT_RING; ++r) {
-            HIP_TRY(hipEventCreateWithFlags(&dev->ev_shaded[r], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&dev->ev_copied[r], hipEventDisableTiming));
-        }
+    // the copy stream, its pinned slots and events are made once per device; a failure half-way is retried from the
+    // piece that is missing
+    if (!dev->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&dev->copy_stream, hipStreamNonBlocking));
+    if (!dev->h_counts)
+        HIP_TRY(hipHostMalloc((void **)&dev->h_counts, rtmi_device::COUNT_RING * per_bounce * sizeof(uint32_t),
+                              hipHostMallocDefault));
+    for (int r = 0; r < rtmi_device::COUNT_RING; ++r) {
+        if (!dev->ev_shaded[r]) HIP_TRY(hipEventCreateWithFlags(&dev->ev_shaded[r], hipEventDisableTiming));
+        if (!dev->ev_copied[r]) HIP_TRY(hipEventCreateWithFlags(&dev->ev_copied[r], hipEventDisableTiming));
     }
     Stopwatch watch;
     float total_ms = 0.0f, bounce_ms = 0.0f, extend_ms = 0.0f;
