@@ -828,8 +828,11 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     uint32_t queue_depths = 2;
     if (const char *v = getenv("RTMI_QUEUE_LOW")) queue_low = std::max(0, std::min(64, atoi(v)));
     if (const char *v = getenv("RTMI_QUEUE_DEPTHS")) queue_depths = (uint32_t)std::max(0, atoi(v));
+    int queue_refill = 48; // refill threshold of that kernel (lanes still traversing or waiting for queued tests)
+    if (const char *v = getenv("RTMI_QUEUE_REFILL")) queue_refill = std::max(1, std::min(64, atoi(v)));
     a.queue_low = 0;
     a.refill_below = std::max(1, std::min(64, a.refill_below)); // below 1 a drained wave would never flush
+    const int vote_refill = a.refill_below;
     a.spill = scene->d_spill;
     const uint32_t full_grid = scene->grid_blocks;
 
@@ -934,6 +937,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             // timed on its own: the traversal launch is what the roofline of the dominant kernel needs
             const int t_extend = watch.start(stream, &extend_ms);
             a.queue_low = depth < queue_depths ? queue_low : 0;
+            a.refill_below = a.queue_low > 0 ? queue_refill : vote_refill;
             int lrc = rtk::launch_extend(a, depth, grid, stream);
             watch.stop(t_extend, stream);
             if (lrc || rtk::launch_shade(a, depth, longest, stream)) {
