@@ -98,7 +98,8 @@ int launch_shade(const RenderArgs &args, uint32_t depth, uint32_t max_segment_en
 // every path alive at bounce depth0 (>= 1) to its end; grid and spill buffer as launch_shade: one thread per entry,
 // so d_spill must cover max_segment_entries * SEGMENTS threads rounded up to blocks
 int launch_tail(const RenderArgs &args, uint32_t depth0, uint32_t max_segment_entries, void *stream);
-int extend_blocks_per_cu(); // resident blocks of the traversal kernel per CU (occupancy query)
+// resident blocks per CU of extend_kernel, or of extend_queue_kernel (occupancy query)
+int extend_blocks_per_cu(bool queued);
 int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, void *stream);
 // d_lin[i] = row-major position of pixel d_xy[i] in the window (ox, oy, w, h); *d_bad |= 1 if a pixel lies outside
 int launch_frame_index(const uint32_t *d_xy, uint32_t n, uint32_t ox, uint32_t oy, uint32_t w, uint32_t h,

@@ -213,6 +213,63 @@ __device__ __forceinline__ uint32_t segment_entries(const RenderArgs &a, uint32_
     return a.counts[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE];
 }
 
+// Wave-uniform cursor of a traversal wave over the queue of one bounce: the segment being drained (the wave starts on
+// the segment of the XCD it runs on and moves on to the others once that one is used up) and the part of that
+// segment's queue the wave has claimed and not yet handed to its lanes.  Every member must be called with all lanes of
+// the wave active.
+struct QueueCursor {
+    uint32_t home, turn, seg, n_in, c_next, c_end;
+    bool drained; // the segment has no unclaimed entries left
+    __device__ __forceinline__ void begin(const RenderArgs &a, uint32_t depth) {
+        home = xcd_of_wave();
+        turn = 0;
+        seg = home;
+        n_in = segment_entries(a, depth, seg);
+        c_next = c_end = 0;
+        drained = n_in == 0u;
+    }
+    // When the claimed range is used up: the next segment that has entries left, and a.claim of them with one atomic.
+    __device__ __forceinline__ void claim(const RenderArgs &a, uint32_t depth) {
+        while (c_next == c_end && drained && turn + 1u < (uint32_t)SEGMENTS) {
+            ++turn;
+            seg = (home + turn) & (uint32_t)(SEGMENTS - 1);
+            n_in = segment_entries(a, depth, seg);
+            drained = n_in == 0u;
+        }
+        if (c_next == c_end && !drained) {
+            uint32_t base = 0;
+            if (rank_in(~0ull) == 0u) base = atomicAdd(&a.work[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE], a.claim);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n_in) {
+                drained = true;
+            } else {
+                c_next = base;
+                c_end = min(base + a.claim, n_in);
+                if (c_end == n_in) drained = true;
+            }
+        }
+    }
+    // Deals the next claimed entries to the lanes that are idle, in lane order; true for a lane that got entry i.
+    __device__ __forceinline__ bool take(bool idle, uint32_t &i) {
+        if (c_next == c_end) return false;
+        const unsigned long long nmask = __ballot(idle);
+        i = c_next + rank_in(nmask);
+        const bool got = idle && i < c_end;
+        c_next = min(c_end, c_next + (uint32_t)__popcll(nmask));
+        return got;
+    }
+    __device__ __forceinline__ bool finished() const { return c_next == c_end && drained && turn + 1u >= (uint32_t)SEGMENTS; }
+};
+
+// Hit record of the queue entry at plane offset `slot`: distance (+inf = miss), geometric normal, geometry word.
+__device__ __forceinline__ void store_hit(float *__restrict__ hits, size_t H, uint32_t slot, float t, V3 ng, uint32_t code) {
+    stp(hits + 0 * H, slot, t);
+    stp(hits + 1 * H, slot, ng.x);
+    stp(hits + 2 * H, slot, ng.y);
+    stp(hits + 3 * H, slot, ng.z);
+    stp(hits + 4 * H, slot, __builtin_bit_cast(float, code));
+}
+
 // Camera rays of every path of a pass, in the implicit queue order of bounce 0, into the bounce's payload planes.
 // Padding entries (pixels past n_pixels, pixels that take no more samples) get a zero direction, which no camera ray
 // has.
@@ -252,13 +309,8 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t de
     float *__restrict__ hits = a.hits;
     const float *__restrict__ Q = a.payload[depth & 1u]; // this bounce's rays, in queue order
     uint32_t nodes = 0, tests = 0;
-    const uint32_t home = xcd_of_wave();
-
-    // wave-uniform: the segment being drained and the part of its queue this wave has claimed and not yet used
-    uint32_t turn = 0, seg = home;
-    uint32_t n_in = segment_entries(a, depth, seg);
-    uint32_t c_next = 0, c_end = 0;
-    bool drained = n_in == 0u; // the segment has no unclaimed entries left
+    QueueCursor cur;
+    cur.begin(a, depth);
 
     bool has_ray = false;
     uint32_t slot_out = 0; // where this lane's hit record goes
@@ -279,54 +331,26 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t de
                     t = tr.best.t;
                     ng = candidate_normal(a.scene, tr.best.slot, org, dir, t, code, geom_first);
                 }
-                stp(hits + 0 * H, slot_out, t);
-                stp(hits + 1 * H, slot_out, ng.x);
-                stp(hits + 2 * H, slot_out, ng.y);
-                stp(hits + 3 * H, slot_out, ng.z);
-                stp(hits + 4 * H, slot_out, __builtin_bit_cast(float, code));
+                store_hit(hits, H, slot_out, t, ng, code);
                 has_ray = false;
             }
-            // ---- move on to the next segment once this one is used up; claim the next a.claim entries with one atomic
-            // when the wave's range is used up
-            while (c_next == c_end && drained && turn + 1u < (uint32_t)SEGMENTS) {
-                ++turn;
-                seg = (home + turn) & (uint32_t)(SEGMENTS - 1);
-                n_in = segment_entries(a, depth, seg);
-                drained = n_in == 0u;
-            }
-            if (c_next == c_end && !drained) {
-                uint32_t base = 0;
-                if (rank_in(~0ull) == 0u) base = atomicAdd(&a.work[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE], a.claim);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n_in) {
-                    drained = true;
-                } else {
-                    c_next = base;
-                    c_end = min(base + a.claim, n_in);
-                    if (c_end == n_in) drained = true;
-                }
-            }
-            // ---- refill idle lanes from the claimed range
-            if (c_next != c_end) {
-                const unsigned long long nmask = __ballot(!has_ray);
-                const uint32_t i = c_next + rank_in(nmask);
-                const bool take = !has_ray && i < c_end;
-                c_next = min(c_end, c_next + (uint32_t)__popcll(nmask));
-                if (take) {
-                    const uint32_t pos = seg * a.seg_cap + i;
-                    org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
-                    dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
-                    if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
-                        slot_out = pos;
-                        st.sp = 0;
-                        trav_begin(a.scene, org, dir, INFINITY, tr);
-                        has_ray = true;
-                    }
+            // ---- refill the idle lanes from the wave's claimed range
+            cur.claim(a, depth);
+            uint32_t i;
+            if (cur.take(!has_ray, i)) {
+                const uint32_t pos = cur.seg * a.seg_cap + i;
+                org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+                dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
+                if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
+                    slot_out = pos;
+                    st.sp = 0;
+                    trav_begin(a.scene, org, dir, INFINITY, tr);
+                    has_ray = true;
                 }
             }
             if (__ballot(has_ray) == 0ull) {
                 // nothing in flight: done when every segment is used up, otherwise take more
-                if (c_next == c_end && drained && turn + 1u >= (uint32_t)SEGMENTS) break;
+                if (cur.finished()) break;
                 continue;
             }
         }
@@ -387,16 +411,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
     const size_t H = (size_t)SEGMENTS * a.seg_cap;
     float *__restrict__ hits = a.hits;
     const float *__restrict__ Q = a.payload[depth & 1u];
-    const uint32_t home = xcd_of_wave();
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u); // wave-uniform, kept in a scalar register
     uint32_t *queue = lds.queue[wave_base >> 6];
     const unsigned long long no_hit = ((unsigned long long)__builtin_bit_cast(uint32_t, INFINITY) << 32) | RT_EMPTY;
-
-    uint32_t turn = 0, seg = home;
-    uint32_t n_in = segment_entries(a, depth, seg);
-    uint32_t c_next = 0, c_end = 0;
-    bool drained = n_in == 0u;
+    QueueCursor cur;
+    cur.begin(a, depth);
 
     // wave-uniform: queue entries tested / appended so far; entry k is at queue[k % QUEUE_CAP]
     uint32_t q_head = 0, q_tail = 0;
@@ -421,56 +441,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
                     const float2 r0 = lds.ray[tid][0], r1 = lds.ray[tid][1], r2 = lds.ray[tid][2];
                     ng = candidate_normal(a.scene, lds.best_slot[tid], mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), t, code, geom_first);
                 }
-                const uint32_t slot_out = lds.slot_out[tid];
-                stp(hits + 0 * H, slot_out, t);
-                stp(hits + 1 * H, slot_out, ng.x);
-                stp(hits + 2 * H, slot_out, ng.y);
-                stp(hits + 3 * H, slot_out, ng.z);
-                stp(hits + 4 * H, slot_out, __builtin_bit_cast(float, code));
+                store_hit(hits, H, lds.slot_out[tid], t, ng, code);
                 has_ray = false;
             }
-            while (c_next == c_end && drained && turn + 1u < (uint32_t)SEGMENTS) {
-                ++turn;
-                seg = (home + turn) & (uint32_t)(SEGMENTS - 1);
-                n_in = segment_entries(a, depth, seg);
-                drained = n_in == 0u;
-            }
-            if (c_next == c_end && !drained) {
-                uint32_t base = 0;
-                if (rank_in(~0ull) == 0u) base = atomicAdd(&a.work[(size_t)(depth * SEGMENTS + seg) * COUNTER_STRIDE], a.claim);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n_in) {
-                    drained = true;
-                } else {
-                    c_next = base;
-                    c_end = min(base + a.claim, n_in);
-                    if (c_end == n_in) drained = true;
-                }
-            }
-            if (c_next != c_end) {
-                const unsigned long long nmask = __ballot(!has_ray);
-                const uint32_t i = c_next + rank_in(nmask);
-                const bool take = !has_ray && i < c_end;
-                c_next = min(c_end, c_next + (uint32_t)__popcll(nmask));
-                if (take) {
-                    const uint32_t pos = seg * a.seg_cap + i;
-                    const V3 org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
-                    const V3 dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
-                    if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
-                        lds.slot_out[tid] = pos;
-                        st.sp = 0;
-                        trav_begin(a.scene, org, dir, INFINITY, tr);
-                        lds.ray[tid][0] = make_float2(org.x, org.y);
-                        lds.ray[tid][1] = make_float2(org.z, dir.x);
-                        lds.ray[tid][2] = make_float2(dir.y, dir.z);
-                        lds.best[tid] = no_hit;
-                        last_post = q_head;
-                        has_ray = true;
-                    }
+            cur.claim(a, depth);
+            uint32_t i;
+            if (cur.take(!has_ray, i)) {
+                const uint32_t pos = cur.seg * a.seg_cap + i;
+                const V3 org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+                const V3 dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
+                if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
+                    lds.slot_out[tid] = pos;
+                    st.sp = 0;
+                    trav_begin(a.scene, org, dir, INFINITY, tr);
+                    lds.ray[tid][0] = make_float2(org.x, org.y);
+                    lds.ray[tid][1] = make_float2(org.z, dir.x);
+                    lds.ray[tid][2] = make_float2(dir.y, dir.z);
+                    lds.best[tid] = no_hit;
+                    last_post = q_head;
+                    has_ray = true;
                 }
             }
             if (__ballot(has_ray) == 0ull) {
-                if (c_next == c_end && drained && turn + 1u >= (uint32_t)SEGMENTS) break;
+                if (cur.finished()) break;
                 continue;
             }
         }
@@ -930,11 +923,11 @@ int launch_raygen(const RenderArgs &args, void *stream) {
     return check_launch();
 }
 
-int extend_blocks_per_cu() {
-    int n = 0, m = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, extend_kernel, BLOCK, 0) != hipSuccess || n < 1) n = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, extend_queue_kernel, BLOCK, 0) != hipSuccess || m < 1) m = 1;
-    return n > m ? n : m; // the grid of either kernel: more blocks than fit just wait their turn
+int extend_blocks_per_cu(bool queued) {
+    int n = 0;
+    const hipError_t e = queued ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, extend_queue_kernel, BLOCK, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, extend_kernel, BLOCK, 0);
+    return e == hipSuccess && n >= 1 ? n : 1;
 }
 
 int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, void *stream) {

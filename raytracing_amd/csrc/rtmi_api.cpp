@@ -375,7 +375,10 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
                       hipMemcpyHostToDevice));
     // resident grid of the traversal kernel (its LDS stack and registers bound the blocks per CU)
     {
-        scene->grid_blocks = (uint32_t)dev->n_cu * (uint32_t)rtk::extend_blocks_per_cu();
+        const uint32_t per_cu = (uint32_t)rtk::extend_blocks_per_cu(false), per_cu_q = (uint32_t)rtk::extend_blocks_per_cu(true);
+        scene->grid_blocks = (uint32_t)dev->n_cu * std::max(per_cu, per_cu_q);
+        scene->grid_blocks_vote = (uint32_t)dev->n_cu * per_cu;
+        scene->grid_blocks_queue = (uint32_t)dev->n_cu * per_cu_q;
         const size_t deep = bvh.stack_need > (uint32_t)rtk::SPILL_FROM ? bvh.stack_need - rtk::SPILL_FROM : 0;
         scene->spill_bytes = std::max<size_t>(16, deep * scene->grid_blocks * rtk::BLOCK * sizeof(uint32_t));
         HIP_TRY(hipMalloc((void **)&scene->d_spill, scene->spill_bytes));
@@ -929,14 +932,15 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             }
             // grid sized to the work: one wave per 64 queue entries, capped at the resident grid; a wave claims
             // several batches per atomic when the queue is long
+            a.queue_low = depth < queue_depths ? queue_low : 0;
+            const uint32_t resident = a.queue_low > 0 && a.visit_counters == nullptr ? scene->grid_blocks_queue : scene->grid_blocks_vote;
             const uint64_t entries = depth == 0 ? (uint64_t)a.n_paths : live;
             const uint64_t want_blocks = (entries + 64 * waves_per_block - 1) / (64 * waves_per_block);
-            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full_grid, want_blocks));
+            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(resident, want_blocks));
             const uint64_t per_wave = entries / ((uint64_t)grid * waves_per_block * rtk::SEGMENTS) / 8;
             a.claim = 64u * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, per_wave / 64));
             // timed on its own: the traversal launch is what the roofline of the dominant kernel needs
             const int t_extend = watch.start(stream, &extend_ms);
-            a.queue_low = depth < queue_depths ? queue_low : 0;
             a.refill_below = a.queue_low > 0 ? queue_refill : vote_refill;
             int lrc = rtk::launch_extend(a, depth, grid, stream);
             watch.stop(t_extend, stream);
