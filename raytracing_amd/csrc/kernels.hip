@@ -3,6 +3,7 @@
 //   intersect_kernel   batch closest hit (Shape::intersection_full for n rays)
 //   raygen_kernel      camera rays of every path of a pass
 //   extend_kernel      closest hit of every live path's ray at one bounce (persistent waves, lanes refill themselves)
+//   extend_queue_kernel  the same with the record tests deferred into a per-wave queue (used for the first bounces)
 //   shade_kernel       scatter / terminate every path from its hit record, compact the survivors into the next
 //                      bounce's queue
 //   tail_kernel        the last few paths of a pass, each run to its end in one launch
