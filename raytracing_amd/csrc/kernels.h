@@ -95,9 +95,10 @@ int launch_raygen(const RenderArgs &args, void *stream); // camera rays of a pas
 int launch_extend(const RenderArgs &args, uint32_t depth, uint32_t grid_blocks, void *stream);
 // one thread per queue entry; max_segment_entries = the longest segment's entry count at this bounce
 int launch_shade(const RenderArgs &args, uint32_t depth, uint32_t max_segment_entries, void *stream);
-// every path alive at bounce depth0 (>= 1) to its end; grid and spill buffer as launch_shade: one thread per entry,
-// so d_spill must cover max_segment_entries * SEGMENTS threads rounded up to blocks
-int launch_tail(const RenderArgs &args, uint32_t depth0, uint32_t max_segment_entries, void *stream);
+// every path alive at bounce depth0 (>= 1) to its end, by persistent waves that take the paths from the queue of that
+// bounce (args.claim entries per atomic); d_spill must cover grid_blocks * BLOCK threads
+int launch_tail(const RenderArgs &args, uint32_t depth0, uint32_t grid_blocks, void *stream);
+int tail_blocks_per_cu(); // resident blocks of tail_kernel per CU (occupancy query)
 // resident blocks per CU of extend_kernel, or of extend_queue_kernel (occupancy query)
 int extend_blocks_per_cu(bool queued);
 int launch_accumulate(const RenderArgs &args, float *d_accum, float count_inc, void *stream);

@@ -653,82 +653,105 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
 }
 
 // The thin tail of a pass: once few paths are left, a launch per bounce costs more than the bounce (the kernels are
-// latency-bound with a few thousand rays), so this kernel takes every path still alive at bounce `depth0` and runs it
-// to its end, one path per lane: closest hit, shading, next ray, in the same per-ray functions as the two kernels
-// above (results do not depend on which kernel traces a path).  Every bounce the wave adds its live lanes to the
-// counter of that bounce, so the counters read like those of the wavefront kernels.
+// latency-bound with a few hundred thousand rays: the slowest ray of a wave takes ~150 dependent steps), so this kernel
+// takes every path still alive at bounce `depth0` and runs it to its end, one path per lane: closest hit, shading, next
+// ray, in the same per-ray functions as the kernels above (results do not depend on which kernel traces a path).  Waves
+// are persistent and their lanes independent: every iteration the wave runs the one phase -- inner-node step, record
+// test, or shading of the rays whose traversal is over -- that most of its lanes wait for, and lanes whose path has
+// ended take the next entries of the queue of bounce depth0, so the launch lasts about as long as the deepest path
+// while the other lanes work through the short ones.  After every shading phase the wave adds its surviving lanes to
+// the counters of the bounces they enter, so the counters read like those of the wavefront kernels.
 __global__ __launch_bounds__(BLOCK) void tail_kernel(RenderArgs a, uint32_t depth0) {
     __shared__ uint32_t lds[LDS_STACK * BLOCK];
     LaneStack st = make_stack(lds, a.spill);
-    const uint32_t seg = blockIdx.x % (uint32_t)SEGMENTS;
-    const uint32_t i = (blockIdx.x / (uint32_t)SEGMENTS) * (uint32_t)BLOCK + threadIdx.x;
-    const uint32_t n_in = segment_entries(a, depth0, seg);
     const size_t P = a.n_paths;
     const size_t H = (size_t)SEGMENTS * a.seg_cap;
     float *__restrict__ S = a.state;
     const float *__restrict__ Q = a.payload[depth0 & 1u];
-    const uint32_t pos = seg * a.seg_cap + i;
-    bool alive = i < n_in;
-    uint32_t pid = 0, x = 0, y = 0, sample = 0;
+    QueueCursor cur;
+    cur.begin(a, depth0);
+    bool alive = false;
+    uint32_t pid = 0, x = 0, y = 0, sample = 0, depth = depth0;
     V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f), beta = mk(0.0f, 0.0f, 0.0f);
     float ray_depth = 0.0f;
-    if (alive) {
-        const Entry e = queue_entry(a, depth0, seg, i, Q + (size_t)seg * a.seg_cap);
-        pid = e.pid;
-        sample = e.sample;
-        x = a.pixels[2 * e.pix];
-        y = a.pixels[2 * e.pix + 1];
-        org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
-        dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
-        beta = mk(ldp(Q + 7 * H, pos), ldp(Q + 8 * H, pos), ldp(Q + 9 * H, pos));
-        ray_depth = ldp(Q + 10 * H, pos);
-    }
-    for (uint32_t depth = depth0; depth < a.max_depth; ++depth) {
-        // closest hit of the wave's live rays, in node / record phases like extend_kernel (no refill: the wave's rays
-        // of one bounce start together)
-        Trav tr;
-        tr.cur = RT_EMPTY;
-        if (alive) {
-            st.sp = 0;
-            trav_begin(a.scene, org, dir, INFINITY, tr);
-        }
-        for (;;) {
-            st.note_depth();
-            const bool at_leaf = tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
-            const bool at_node = tr.cur != RT_EMPTY && !at_leaf;
-            const int n_node = (int)__popcll(__ballot(at_node));
-            const int n_leaf = (int)__popcll(__ballot(at_leaf));
-            if (n_node + n_leaf == 0) break;
-            if (n_leaf == 0 || (n_node > 0 && n_node >= n_leaf)) {
-                if (at_node) trav_node_step(a.scene, RT_TNEAR, tr, st);
-            } else {
-                if (at_leaf) trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
+    Trav tr;
+    tr.cur = RT_EMPTY;
+    bool exhausted = false; // wave-uniform: every entry of the queue has been handed out
+    for (;;) {
+        // ---- idle lanes take the next paths of the queue, while it has any
+        if (!exhausted && (int)__popcll(__ballot(alive)) < a.refill_below) {
+            cur.claim(a, depth0);
+            uint32_t i;
+            if (cur.take(!alive, i)) {
+                const uint32_t pos = cur.seg * a.seg_cap + i;
+                const Entry e = queue_entry(a, depth0, cur.seg, i, Q + (size_t)cur.seg * a.seg_cap);
+                pid = e.pid;
+                sample = e.sample;
+                x = a.pixels[2 * e.pix];
+                y = a.pixels[2 * e.pix + 1];
+                org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+                dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
+                beta = mk(ldp(Q + 7 * H, pos), ldp(Q + 8 * H, pos), ldp(Q + 9 * H, pos));
+                ray_depth = ldp(Q + 10 * H, pos);
+                depth = depth0;
+                st.sp = 0;
+                trav_begin(a.scene, org, dir, INFINITY, tr);
+                alive = true;
             }
+            exhausted = cur.finished();
         }
-        if (alive) {
-            const Closest best = tr.best;
-            HitInfo h;
-            finish_hit(a.scene, org, dir, best, h);
-            VertexOut vo;
-            bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, x, y, sample, depth, org, dir, beta, vo);
-            if (h.hit && vo.t_add != 0.0f) ray_depth = ray_depth + vo.t_add;
-            if (cont && depth + 1u == a.max_depth) {
-                // the next vertex would be at the depth limit: it contributes beta * 0 (pathtracing.rs:24-26)
-                vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
-                cont = false;
-            }
-            if (!cont) {
-                stp(S + 0 * P, pid, vo.radiance.x);
-                stp(S + 1 * P, pid, vo.radiance.y);
-                stp(S + 2 * P, pid, vo.radiance.z);
-                stp(S + 13 * P, pid, ray_depth);
-                alive = false;
-            }
+        if (__ballot(alive) == 0ull) {
+            if (exhausted) break;
+            continue;
         }
-        const unsigned long long amask = __ballot(alive);
-        if (amask == 0ull) break;
-        if (rank_in(~0ull) == 0u)
-            atomicAdd(&a.counts[(size_t)((depth + 1u) * SEGMENTS + seg) * COUNTER_STRIDE], (uint32_t)__popcll(amask));
+        // ---- the phase most lanes wait for: a lane with a path is at an inner node, at a record, or through with its
+        // traversal and waiting to be shaded
+        st.note_depth();
+        const bool at_leaf = alive && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
+        const bool at_node = alive && tr.cur != RT_EMPTY && !at_leaf;
+        const bool at_shade = alive && tr.cur == RT_EMPTY;
+        const int n_node = (int)__popcll(__ballot(at_node));
+        const int n_leaf = (int)__popcll(__ballot(at_leaf));
+        const int n_shade = (int)__popcll(__ballot(at_shade));
+        if (n_shade >= n_node && n_shade >= n_leaf) {
+            if (at_shade) {
+                const Closest best = tr.best;
+                HitInfo h;
+                finish_hit(a.scene, org, dir, best, h);
+                VertexOut vo;
+                bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, x, y, sample, depth, org, dir, beta, vo);
+                if (h.hit && vo.t_add != 0.0f) ray_depth = ray_depth + vo.t_add;
+                if (cont && depth + 1u == a.max_depth) {
+                    // the next vertex would be at the depth limit: it contributes beta * 0 (pathtracing.rs:24-26)
+                    vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
+                    cont = false;
+                }
+                if (!cont) {
+                    stp(S + 0 * P, pid, vo.radiance.x);
+                    stp(S + 1 * P, pid, vo.radiance.y);
+                    stp(S + 2 * P, pid, vo.radiance.z);
+                    stp(S + 13 * P, pid, ray_depth);
+                    alive = false;
+                } else {
+                    ++depth;
+                    st.sp = 0;
+                    trav_begin(a.scene, org, dir, INFINITY, tr);
+                }
+            }
+            // one counter update per distinct depth among the lanes that go on
+            unsigned long long todo = __ballot(at_shade && alive);
+            while (todo != 0ull) {
+                const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)depth, (int)__builtin_ctzll(todo));
+                const unsigned long long same = __ballot(at_shade && alive && depth == d);
+                if (rank_in(~0ull) == 0u)
+                    atomicAdd(&a.counts[(size_t)(d * SEGMENTS + cur.home) * COUNTER_STRIDE], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        } else if (n_node >= n_leaf) {
+            if (at_node) trav_node_step(a.scene, RT_TNEAR, tr, st);
+        } else {
+            if (at_leaf) trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
+        }
     }
 }
 
@@ -908,12 +931,16 @@ int launch_shade(const RenderArgs &args, uint32_t depth, uint32_t max_segment_en
     return check_launch();
 }
 
-int launch_tail(const RenderArgs &args, uint32_t depth0, uint32_t max_segment_entries, void *stream) {
-    if (max_segment_entries == 0) return 0;
+int launch_tail(const RenderArgs &args, uint32_t depth0, uint32_t grid_blocks, void *stream) {
+    if (grid_blocks == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const uint32_t per_seg = (max_segment_entries + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(tail_kernel, dim3(per_seg * SEGMENTS), dim3(BLOCK), 0, s, args, depth0);
+    hipLaunchKernelGGL(tail_kernel, dim3(grid_blocks), dim3(BLOCK), 0, s, args, depth0);
     return check_launch();
+}
+
+int tail_blocks_per_cu() {
+    int n = 0;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_kernel, BLOCK, 0) == hipSuccess && n >= 1 ? n : 1;
 }
 
 int launch_raygen(const RenderArgs &args, void *stream) {

@@ -379,6 +379,7 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
         scene->grid_blocks = (uint32_t)dev->n_cu * std::max(per_cu, per_cu_q);
         scene->grid_blocks_vote = (uint32_t)dev->n_cu * per_cu;
         scene->grid_blocks_queue = (uint32_t)dev->n_cu * per_cu_q;
+        scene->grid_blocks_tail = std::min(scene->grid_blocks, (uint32_t)dev->n_cu * (uint32_t)rtk::tail_blocks_per_cu());
         const size_t deep = bvh.stack_need > (uint32_t)rtk::SPILL_FROM ? bvh.stack_need - rtk::SPILL_FROM : 0;
         scene->spill_bytes = std::max<size_t>(16, deep * scene->grid_blocks * rtk::BLOCK * sizeof(uint32_t));
         HIP_TRY(hipMalloc((void **)&scene->d_spill, scene->spill_bytes));
@@ -831,13 +832,14 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     uint32_t queue_depths = 2;
     if (const char *v = getenv("RTMI_QUEUE_LOW")) queue_low = std::max(0, std::min(64, atoi(v)));
     if (const char *v = getenv("RTMI_QUEUE_DEPTHS")) queue_depths = (uint32_t)std::max(0, atoi(v));
+    int tail_refill = 64; // lanes with a path below which a wave of the tail kernel takes new paths (64: as soon as one is idle)
+    if (const char *v = getenv("RTMI_TAIL_REFILL")) tail_refill = std::max(1, std::min(64, atoi(v)));
     int queue_refill = 48; // refill threshold of that kernel (lanes still traversing or waiting for queued tests)
     if (const char *v = getenv("RTMI_QUEUE_REFILL")) queue_refill = std::max(1, std::min(64, atoi(v)));
     a.queue_low = 0;
     a.refill_below = std::max(1, std::min(64, a.refill_below)); // below 1 a drained wave would never flush
-    const int vote_refill = a.refill_below;
+    const int vote_refill = a.refill_below, vote_bias = a.leaf_bias;
     a.spill = scene->d_spill;
-    const uint32_t full_grid = scene->grid_blocks;
 
     // the copy stream, its pinned slots and events are made once per device; a failure half-way is retried from the
     // piece that is missing
@@ -856,7 +858,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     int rc = RTMI_OK;
     uint32_t sample = params->sample_begin;
     uint64_t rays = 0, paths = 0, tail_rays_traced = 0;
-    uint64_t tail_rays = 1u << 18;
+    uint64_t tail_rays = 1u << 22;
     if (const char *v = getenv("RTMI_TAIL_RAYS")) tail_rays = (uint64_t)atoll(v);
     uint32_t deepest = 0, launches = 0;
     uint32_t n_done = 0; // pixels already precise enough for this call (use_done only)
@@ -923,9 +925,13 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
                 if (live == 0) break; // bounce depth - 1 already ran on an empty queue
                 expected = (uint64_t)((double)live * (double)live / (double)std::max<uint64_t>(before, 1));
             }
-            if (depth > 0 && expected < tail_rays &&
-                (uint64_t)((longest + rtk::BLOCK - 1) / rtk::BLOCK) * rtk::SEGMENTS <= full_grid) {
-                if (rtk::launch_tail(a, depth, longest, stream)) rc = fail(RTMI_ERR_DEVICE, "tail kernel launch failed");
+            if (depth > 0 && expected < tail_rays) {
+                // persistent waves: a resident grid at most, one lane per path when there are fewer paths than that
+                const uint64_t want = (live + rtk::BLOCK - 1) / rtk::BLOCK;
+                a.claim = 64u;
+                a.refill_below = tail_refill;
+                if (rtk::launch_tail(a, depth, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(scene->grid_blocks_tail, want)), stream))
+                    rc = fail(RTMI_ERR_DEVICE, "tail kernel launch failed");
                 tail_from = depth;
                 launched = params->max_depth;
                 break;
@@ -942,6 +948,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             // timed on its own: the traversal launch is what the roofline of the dominant kernel needs
             const int t_extend = watch.start(stream, &extend_ms);
             a.refill_below = a.queue_low > 0 ? queue_refill : vote_refill;
+            a.leaf_bias = vote_bias;
             int lrc = rtk::launch_extend(a, depth, grid, stream);
             watch.stop(t_extend, stream);
             if (lrc || rtk::launch_shade(a, depth, longest, stream)) {

@@ -117,6 +117,7 @@ struct rtmi_scene {
     uint32_t grid_blocks = 0;    // resident grid the spill buffers are sized for (the larger of the two traversal kernels')
     uint32_t grid_blocks_vote = 0;  // resident grid of extend_kernel
     uint32_t grid_blocks_queue = 0; // resident grid of extend_queue_kernel
+    uint32_t grid_blocks_tail = 0;  // resident grid of tail_kernel
     rtd::SceneView view{};
     // rtmi_intersect_device launches on caller-chosen streams, possibly several at once: each launch takes the next
     // of a few spill buffers of its own and leaves an event behind; the launch that takes the buffer next waits for
