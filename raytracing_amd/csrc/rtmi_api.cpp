@@ -834,6 +834,8 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     if (const char *v = getenv("RTMI_QUEUE_DEPTHS")) queue_depths = (uint32_t)std::max(0, atoi(v));
     int tail_refill = 64; // lanes with a path below which a wave of the tail kernel takes new paths (64: as soon as one is idle)
     if (const char *v = getenv("RTMI_TAIL_REFILL")) tail_refill = std::max(1, std::min(64, atoi(v)));
+    int tail_shade = 32; // lanes waiting for shading that make a wave of the tail kernel shade (0: when they are the majority)
+    if (const char *v = getenv("RTMI_TAIL_SHADE")) tail_shade = std::max(0, std::min(64, atoi(v)));
     int queue_refill = 48; // refill threshold of that kernel (lanes still traversing or waiting for queued tests)
     if (const char *v = getenv("RTMI_QUEUE_REFILL")) queue_refill = std::max(1, std::min(64, atoi(v)));
     a.queue_low = 0;
@@ -930,6 +932,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
                 const uint64_t want = (live + rtk::BLOCK - 1) / rtk::BLOCK;
                 a.claim = 64u;
                 a.refill_below = tail_refill;
+                a.leaf_bias = tail_shade;
                 if (rtk::launch_tail(a, depth, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(scene->grid_blocks_tail, want)), stream))
                     rc = fail(RTMI_ERR_DEVICE, "tail kernel launch failed");
                 tail_from = depth;
