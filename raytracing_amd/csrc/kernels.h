@@ -72,6 +72,7 @@ struct RenderArgs {
     uint32_t claim;       // queue entries a wave claims with one atomic (a multiple of 64)
     int32_t refill_below; // a traversal wave flushes finished lanes and refills when fewer lanes than this are busy
     int32_t leaf_bias;    // a primitive-test step is run when leaf lanes + bias > node lanes
+    int32_t tail_shade;   // tail_kernel shades once this many lanes of a wave wait for it (0: when they are the majority)
     int32_t queue_low;    // > 0: traversal defers record tests into a per-wave queue and also tests records when fewer
                           // lanes than this have an inner node to visit; 0: the wave votes on its phase every step
     float allowed_error;  // > 0: a pixel stops accumulating within this pass once its colour error is below it

@@ -713,8 +713,8 @@ __global__ __launch_bounds__(BLOCK) void tail_kernel(RenderArgs a, uint32_t dept
         const int n_node = (int)__popcll(__ballot(at_node));
         const int n_leaf = (int)__popcll(__ballot(at_leaf));
         const int n_shade = (int)__popcll(__ballot(at_shade));
-        // shading costs several node steps, so it waits until a.leaf_bias lanes want it (or nothing else can run)
-        const bool shade_now = a.leaf_bias > 0 ? (n_shade >= a.leaf_bias || n_node + n_leaf == 0) : (n_shade >= n_node && n_shade >= n_leaf);
+        // shading costs several node steps, so it waits until a.tail_shade lanes want it (or nothing else can run)
+        const bool shade_now = a.tail_shade > 0 ? (n_shade >= a.tail_shade || n_node + n_leaf == 0) : (n_shade >= n_node && n_shade >= n_leaf);
         if (shade_now) {
             if (at_shade) {
                 const Closest best = tr.best;

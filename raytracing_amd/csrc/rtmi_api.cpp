@@ -840,7 +840,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     if (const char *v = getenv("RTMI_QUEUE_REFILL")) queue_refill = std::max(1, std::min(64, atoi(v)));
     a.queue_low = 0;
     a.refill_below = std::max(1, std::min(64, a.refill_below)); // below 1 a drained wave would never flush
-    const int vote_refill = a.refill_below, vote_bias = a.leaf_bias;
+    const int vote_refill = a.refill_below;
     a.spill = scene->d_spill;
 
     // the copy stream, its pinned slots and events are made once per device; a failure half-way is retried from the
@@ -932,7 +932,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
                 const uint64_t want = (live + rtk::BLOCK - 1) / rtk::BLOCK;
                 a.claim = 64u;
                 a.refill_below = tail_refill;
-                a.leaf_bias = tail_shade;
+                a.tail_shade = tail_shade;
                 if (rtk::launch_tail(a, depth, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(scene->grid_blocks_tail, want)), stream))
                     rc = fail(RTMI_ERR_DEVICE, "tail kernel launch failed");
                 tail_from = depth;
@@ -951,7 +951,6 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             // timed on its own: the traversal launch is what the roofline of the dominant kernel needs
             const int t_extend = watch.start(stream, &extend_ms);
             a.refill_below = a.queue_low > 0 ? queue_refill : vote_refill;
-            a.leaf_bias = vote_bias;
             int lrc = rtk::launch_extend(a, depth, grid, stream);
             watch.stop(t_extend, stream);
             if (lrc || rtk::launch_shade(a, depth, longest, stream)) {
