@@ -371,6 +371,10 @@ def main():
                               "gathered, not flops",
                 "launches_per_step": n_launch,
                 "avg_launch_ms": extend_ms / max(launches, 1),
+                # the counters' side of the same launch: HBM bytes actually moved per second (the top of the tree is
+                # served by L2, so the algorithmic rate above can exceed what HBM delivers, and even its peak)
+                "traffic_rate_gbs": (traffic / (extend_ms / max(launches, 1) * 1e-3) / 1e9) if traffic else None,
+                "traffic_frac": (traffic / (extend_ms / max(launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "kernel_ms_per_step": extend_ms / steps,
                 "other_kernels_ms_per_step": (gpu_ms - extend_ms) / steps,
                 "algorithmic_bytes_per_step": alg_bytes,

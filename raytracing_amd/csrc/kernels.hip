@@ -6,7 +6,7 @@
 //   extend_queue_kernel  the same with the record tests deferred into a per-wave queue (used for the first bounces)
 //   shade_kernel       scatter / terminate every path from its hit record, compact the survivors into the next
 //                      bounce's queue
-//   tail_kernel        the last few paths of a pass, each run to its end in one launch
+//   tail_kernel        every path still alive once a bounce no longer fills the GPU, each run to its end in one launch
 //   accumulate_kernel  adds a pass's samples to the per-pixel accumulators, in sample order
 //   resolve_kernel     accumulators -> the seven output channels
 //
@@ -54,6 +54,7 @@ struct LaneStackT {
     __device__ __forceinline__ void note_depth() { shallow = __ballot(sp > N - 4) == 0ull; }
 };
 typedef LaneStackT<LDS_STACK> LaneStack;
+typedef LaneStackT<QUEUE_STACK> QueueStack; // of the kernels that keep a queue of record tests in LDS as well
 
 template <int N>
 __device__ __forceinline__ LaneStackT<N> make_stack_of(uint32_t *lds, uint32_t *spill) {
@@ -405,43 +406,128 @@ struct ExtendQueueLds {
 };
 static_assert(RT_MAX_ITEMS <= (1u << 26), "a queue entry keeps the record slot in 26 bits");
 
+// The queue of one wave (wave-uniform counters; entry k is at entries[k % QUEUE_CAP]) and the three things a wave does
+// with it.  Every member must be called with all lanes of the wave active.
+struct WaveQueue {
+    uint32_t *entries;
+    uint32_t head, tail; // entries tested / appended so far
+    __device__ __forceinline__ uint32_t length() const { return tail - head; }
+    // Lanes at a leaf append it (while there is room) and go on with their next stack entry.  last_post = `tail` right
+    // after the lane's latest entry: the lane has tests outstanding while `head` is below it.
+    __device__ __forceinline__ void post(bool has_ray, uint32_t lane, Trav &tr, QueueStack &st, uint32_t &last_post) {
+        const bool at_leaf = has_ray && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
+        const unsigned long long lmask = __ballot(at_leaf);
+        if (lmask == 0ull) return;
+        const uint32_t room = (uint32_t)QUEUE_CAP - (tail - head);
+        const uint32_t r = rank_in(lmask);
+        if (at_leaf && r < room) {
+            const uint32_t first = tr.cur & 0x0FFFFFFFu, more = (tr.cur >> 28) & 7u;
+            entries[(tail + r) & (uint32_t)(QUEUE_CAP - 1)] = (lane << 26) | first;
+            last_post = tail + r + 1u;
+            if (more != 0u)
+                tr.cur = RT_LEAF | ((more - 1u) << 28) | (first + 1u);
+            else
+                tr.cur = st.empty() ? RT_EMPTY : st.pop();
+        }
+        tail += min((uint32_t)__popcll(lmask), room);
+    }
+    __device__ __forceinline__ bool outstanding(uint32_t last_post) const { return (int32_t)(last_post - head) > 0; }
+    // The oldest entries, one per lane: the owner's ray from LDS, the record test, the candidate merged into the
+    // owner's best hit; the lane whose candidate is the owner's best after every lane's minimum records its slot.
+    __device__ __forceinline__ void test(ExtendQueueLds &lds, const SceneView &scene, uint32_t wave_base, uint32_t lane) {
+        const uint32_t take = min(length(), 64u);
+        if (lane < take) {
+            const uint32_t e = entries[(head + lane) & (uint32_t)(QUEUE_CAP - 1)];
+            const uint32_t owner = wave_base + (e >> 26);
+            const float2 r0 = lds.ray[owner][0], r1 = lds.ray[owner][1], r2 = lds.ray[owner][2];
+            const V3 o = mk(r0.x, r0.y, r1.x), d = mk(r1.y, r2.x, r2.y);
+            Closest c;
+            c.t = INFINITY;
+            c.gidx = RT_EMPTY;
+            c.slot = 0;
+            c.u = c.v = 0.0f;
+            test_prim(scene, e & 0x03FFFFFFu, o, d, RT_TNEAR, c);
+            if (c.gidx != RT_EMPTY) {
+                const unsigned long long key = ((unsigned long long)__builtin_bit_cast(uint32_t, c.t) << 32) | c.gidx;
+                atomicMin(&lds.best[owner], key);
+                if (lds.best[owner] == key) lds.best_slot[owner] = c.slot;
+            }
+        }
+        head += take;
+    }
+    // A record phase is due: a wave's worth of tests is waiting, the queue is about to overflow, too few lanes have an
+    // inner node to visit, or nothing else is left to do.
+    __device__ __forceinline__ bool due(uint32_t n_node, uint32_t n_leaf, uint32_t low) const {
+        const uint32_t q_len = length();
+        return q_len >= 64u || q_len + n_leaf > (uint32_t)QUEUE_CAP || (n_node == 0u && n_leaf == 0u && q_len > 0u) ||
+               (n_node < q_len && n_node < low);
+    }
+};
+
+// Inner-node step of a lane whose ray and best hit live in LDS: the best distance as the queued tests have left it,
+// and -origin / direction recomputed from the origin (the same operations trav_begin does: three registers fewer to
+// carry through the record phases).
+__device__ __forceinline__ void queued_node_step(ExtendQueueLds &lds, const SceneView &scene, uint32_t tid, Trav &tr, QueueStack &st) {
+    tr.best.t = __builtin_bit_cast(float, reinterpret_cast<const uint32_t *>(&lds.best[tid])[1]);
+    const float2 r0 = lds.ray[tid][0], r1 = lds.ray[tid][1];
+    tr.nox = -(r0.x * tr.ix);
+    tr.noy = -(r0.y * tr.iy);
+    tr.noz = -(r1.x * tr.iz);
+    trav_node_step(scene, RT_TNEAR, tr, st);
+}
+
+// A lane takes a ray: ray and an empty best hit into LDS, traversal state at the root.
+__device__ __forceinline__ void queued_begin(ExtendQueueLds &lds, const SceneView &scene, uint32_t tid, V3 org, V3 dir, Trav &tr, QueueStack &st) {
+    st.sp = 0;
+    trav_begin(scene, org, dir, INFINITY, tr);
+    lds.ray[tid][0] = make_float2(org.x, org.y);
+    lds.ray[tid][1] = make_float2(org.z, dir.x);
+    lds.ray[tid][2] = make_float2(dir.y, dir.z);
+    lds.best[tid] = ((unsigned long long)__builtin_bit_cast(uint32_t, INFINITY) << 32) | RT_EMPTY;
+}
+
+// The closest hit the queued tests have left for a lane: distance (+inf = none), geometric normal, geometry word.
+__device__ __forceinline__ void queued_result(ExtendQueueLds &lds, const SceneView &scene, uint32_t tid, float &t, V3 &ng, uint32_t &code, V3 &org, V3 &dir) {
+    const unsigned long long key = lds.best[tid];
+    const float2 r0 = lds.ray[tid][0], r1 = lds.ray[tid][1], r2 = lds.ray[tid][2];
+    org = mk(r0.x, r0.y, r1.x);
+    dir = mk(r1.y, r2.x, r2.y);
+    t = INFINITY;
+    ng = mk(0.0f, 0.0f, 0.0f);
+    code = RT_EMPTY;
+    if ((uint32_t)key != RT_EMPTY) {
+        uint32_t geom_first;
+        t = __builtin_bit_cast(float, (uint32_t)(key >> 32));
+        ng = candidate_normal(scene, lds.best_slot[tid], org, dir, t, code, geom_first);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void extend_queue_kernel(RenderArgs a, uint32_t depth) {
     __shared__ ExtendQueueLds lds;
-    LaneStackT<QUEUE_STACK> st = make_stack_of<QUEUE_STACK>(lds.stack, a.spill);
+    QueueStack st = make_stack_of<QUEUE_STACK>(lds.stack, a.spill);
     const bool primary = depth == 0u;
     const size_t H = (size_t)SEGMENTS * a.seg_cap;
     float *__restrict__ hits = a.hits;
     const float *__restrict__ Q = a.payload[depth & 1u];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u); // wave-uniform, kept in a scalar register
-    uint32_t *queue = lds.queue[wave_base >> 6];
-    const unsigned long long no_hit = ((unsigned long long)__builtin_bit_cast(uint32_t, INFINITY) << 32) | RT_EMPTY;
+    WaveQueue wq{lds.queue[wave_base >> 6], 0u, 0u};
     QueueCursor cur;
     cur.begin(a, depth);
-
-    // wave-uniform: queue entries tested / appended so far; entry k is at queue[k % QUEUE_CAP]
-    uint32_t q_head = 0, q_tail = 0;
-    uint32_t last_post = 0; // q_tail right after this lane's latest entry: the lane has tests outstanding while q_head is below it
-
+    uint32_t last_post = 0;
     bool has_ray = false;
     Trav tr;
     tr.cur = RT_EMPTY;
 
     for (;;) {
-        const bool live = has_ray && (tr.cur != RT_EMPTY || (int32_t)(last_post - q_head) > 0);
+        const bool live = has_ray && (tr.cur != RT_EMPTY || wq.outstanding(last_post));
         const int n_live = (int)__popcll(__ballot(live));
         if (n_live < a.refill_below) {
             if (has_ray && !live) {
-                const unsigned long long key = lds.best[tid];
-                const uint32_t gidx = (uint32_t)key;
-                float t = INFINITY;
-                V3 ng = mk(0.0f, 0.0f, 0.0f);
-                uint32_t code = RT_EMPTY, geom_first;
-                if (gidx != RT_EMPTY) {
-                    t = __builtin_bit_cast(float, (uint32_t)(key >> 32));
-                    const float2 r0 = lds.ray[tid][0], r1 = lds.ray[tid][1], r2 = lds.ray[tid][2];
-                    ng = candidate_normal(a.scene, lds.best_slot[tid], mk(r0.x, r0.y, r1.x), mk(r1.y, r2.x, r2.y), t, code, geom_first);
-                }
+                float t;
+                V3 ng, org, dir;
+                uint32_t code;
+                queued_result(lds, a.scene, tid, t, ng, code, org, dir);
                 store_hit(hits, H, lds.slot_out[tid], t, ng, code);
                 has_ray = false;
             }
@@ -453,13 +539,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
                 const V3 dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
                 if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
                     lds.slot_out[tid] = pos;
-                    st.sp = 0;
-                    trav_begin(a.scene, org, dir, INFINITY, tr);
-                    lds.ray[tid][0] = make_float2(org.x, org.y);
-                    lds.ray[tid][1] = make_float2(org.z, dir.x);
-                    lds.ray[tid][2] = make_float2(dir.y, dir.z);
-                    lds.best[tid] = no_hit;
-                    last_post = q_head;
+                    queued_begin(lds, a.scene, tid, org, dir, tr, st);
+                    last_post = wq.head;
                     has_ray = true;
                 }
             }
@@ -469,67 +550,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
             }
         }
         st.note_depth();
-        // ---- lanes at a leaf append it to the queue (while there is room) and go on with their next stack entry
-        {
-            const bool at_leaf = has_ray && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
-            const unsigned long long lmask = __ballot(at_leaf);
-            if (lmask != 0ull) {
-                const uint32_t room = (uint32_t)QUEUE_CAP - (q_tail - q_head);
-                const uint32_t r = rank_in(lmask);
-                if (at_leaf && r < room) {
-                    const uint32_t first = tr.cur & 0x0FFFFFFFu, more = (tr.cur >> 28) & 7u;
-                    queue[(q_tail + r) & (uint32_t)(QUEUE_CAP - 1)] = (lane << 26) | first;
-                    last_post = q_tail + r + 1u;
-                    if (more != 0u)
-                        tr.cur = RT_LEAF | ((more - 1u) << 28) | (first + 1u);
-                    else
-                        tr.cur = st.empty() ? RT_EMPTY : st.pop();
-                }
-                q_tail += min((uint32_t)__popcll(lmask), room);
-            }
-        }
-        // ---- one phase: a record phase when a wave's worth of tests is waiting, the queue is about to overflow, or too
-        // few lanes have an inner node to visit; an inner-node step otherwise
+        wq.post(has_ray, lane, tr, st, last_post);
         const bool at_leaf = has_ray && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
         const bool at_node = has_ray && tr.cur != RT_EMPTY && !at_leaf;
         const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
         const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
-        const uint32_t q_len = q_tail - q_head;
-        const bool record_phase = q_len >= 64u || q_len + n_leaf > (uint32_t)QUEUE_CAP || (n_node == 0u && n_leaf == 0u && q_len > 0u) ||
-                                  (n_node < q_len && n_node < (uint32_t)a.queue_low);
-        if (!record_phase) {
-            if (at_node) {
-                tr.best.t = __builtin_bit_cast(float, reinterpret_cast<const uint32_t *>(&lds.best[tid])[1]);
-                // -origin / direction from the origin in LDS (the same operations trav_begin does): three registers
-                // fewer to carry through the record phases
-                const float2 r0 = lds.ray[tid][0], r1 = lds.ray[tid][1];
-                tr.nox = -(r0.x * tr.ix);
-                tr.noy = -(r0.y * tr.iy);
-                tr.noz = -(r1.x * tr.iz);
-                trav_node_step(a.scene, RT_TNEAR, tr, st);
-            }
-        } else {
-            const uint32_t take = min(q_len, 64u);
-            const bool mine = lane < take;
-            if (mine) {
-                const uint32_t e = queue[(q_head + lane) & (uint32_t)(QUEUE_CAP - 1)];
-                const uint32_t owner = wave_base + (e >> 26);
-                const float2 r0 = lds.ray[owner][0], r1 = lds.ray[owner][1], r2 = lds.ray[owner][2];
-                const V3 o = mk(r0.x, r0.y, r1.x), d = mk(r1.y, r2.x, r2.y);
-                Closest c;
-                c.t = INFINITY;
-                c.gidx = RT_EMPTY;
-                c.slot = 0;
-                c.u = c.v = 0.0f;
-                test_prim(a.scene, e & 0x03FFFFFFu, o, d, RT_TNEAR, c);
-                if (c.gidx != RT_EMPTY) {
-                    const unsigned long long key = ((unsigned long long)__builtin_bit_cast(uint32_t, c.t) << 32) | c.gidx;
-                    atomicMin(&lds.best[owner], key);
-                    // the lane whose candidate is the owner's best after every lane's minimum records where it came from
-                    if (lds.best[owner] == key) lds.best_slot[owner] = c.slot;
-                }
-            }
-            q_head += take;
+        if (wq.due(n_node, n_leaf, (uint32_t)a.queue_low)) {
+            wq.test(lds, a.scene, wave_base, lane);
+        } else if (at_node) {
+            queued_node_step(lds, a.scene, tid, tr, st);
         }
     }
 }
@@ -652,110 +681,6 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
     }
 }
 
-// The thin tail of a pass: once few paths are left, a launch per bounce costs more than the bounce (the kernels are
-// latency-bound with a few hundred thousand rays: the slowest ray of a wave takes ~150 dependent steps), so this kernel
-// takes every path still alive at bounce `depth0` and runs it to its end, one path per lane: closest hit, shading, next
-// ray, in the same per-ray functions as the kernels above (results do not depend on which kernel traces a path).  Waves
-// are persistent and their lanes independent: every iteration the wave runs the one phase -- inner-node step, record
-// test, or shading of the rays whose traversal is over -- that most of its lanes wait for, and lanes whose path has
-// ended take the next entries of the queue of bounce depth0, so the launch lasts about as long as the deepest path
-// while the other lanes work through the short ones.  After every shading phase the wave adds its surviving lanes to
-// the counters of the bounces they enter, so the counters read like those of the wavefront kernels.
-__global__ __launch_bounds__(BLOCK) void tail_kernel(RenderArgs a, uint32_t depth0) {
-    __shared__ uint32_t lds[LDS_STACK * BLOCK];
-    LaneStack st = make_stack(lds, a.spill);
-    const size_t P = a.n_paths;
-    const size_t H = (size_t)SEGMENTS * a.seg_cap;
-    float *__restrict__ S = a.state;
-    const float *__restrict__ Q = a.payload[depth0 & 1u];
-    QueueCursor cur;
-    cur.begin(a, depth0);
-    bool alive = false;
-    uint32_t pid = 0, x = 0, y = 0, sample = 0, depth = depth0;
-    V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 1.0f), beta = mk(0.0f, 0.0f, 0.0f);
-    float ray_depth = 0.0f;
-    Trav tr;
-    tr.cur = RT_EMPTY;
-    bool exhausted = false; // wave-uniform: every entry of the queue has been handed out
-    for (;;) {
-        // ---- idle lanes take the next paths of the queue, while it has any
-        if (!exhausted && (int)__popcll(__ballot(alive)) < a.refill_below) {
-            cur.claim(a, depth0);
-            uint32_t i;
-            if (cur.take(!alive, i)) {
-                const uint32_t pos = cur.seg * a.seg_cap + i;
-                const Entry e = queue_entry(a, depth0, cur.seg, i, Q + (size_t)cur.seg * a.seg_cap);
-                pid = e.pid;
-                sample = e.sample;
-                x = a.pixels[2 * e.pix];
-                y = a.pixels[2 * e.pix + 1];
-                org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
-                dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
-                beta = mk(ldp(Q + 7 * H, pos), ldp(Q + 8 * H, pos), ldp(Q + 9 * H, pos));
-                ray_depth = ldp(Q + 10 * H, pos);
-                depth = depth0;
-                st.sp = 0;
-                trav_begin(a.scene, org, dir, INFINITY, tr);
-                alive = true;
-            }
-            exhausted = cur.finished();
-        }
-        if (__ballot(alive) == 0ull) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---- the phase most lanes wait for: a lane with a path is at an inner node, at a record, or through with its
-        // traversal and waiting to be shaded
-        st.note_depth();
-        const bool at_leaf = alive && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
-        const bool at_node = alive && tr.cur != RT_EMPTY && !at_leaf;
-        const bool at_shade = alive && tr.cur == RT_EMPTY;
-        const int n_node = (int)__popcll(__ballot(at_node));
-        const int n_leaf = (int)__popcll(__ballot(at_leaf));
-        const int n_shade = (int)__popcll(__ballot(at_shade));
-        // shading costs several node steps, so it waits until a.tail_shade lanes want it (or nothing else can run)
-        const bool shade_now = a.tail_shade > 0 ? (n_shade >= a.tail_shade || n_node + n_leaf == 0) : (n_shade >= n_node && n_shade >= n_leaf);
-        if (shade_now) {
-            if (at_shade) {
-                const Closest best = tr.best;
-                HitInfo h;
-                finish_hit(a.scene, org, dir, best, h);
-                VertexOut vo;
-                bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, x, y, sample, depth, org, dir, beta, vo);
-                if (h.hit && vo.t_add != 0.0f) ray_depth = ray_depth + vo.t_add;
-                if (cont && depth + 1u == a.max_depth) {
-                    // the next vertex would be at the depth limit: it contributes beta * 0 (pathtracing.rs:24-26)
-                    vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
-                    cont = false;
-                }
-                if (!cont) {
-                    stp(S + 0 * P, pid, vo.radiance.x);
-                    stp(S + 1 * P, pid, vo.radiance.y);
-                    stp(S + 2 * P, pid, vo.radiance.z);
-                    stp(S + 13 * P, pid, ray_depth);
-                    alive = false;
-                } else {
-                    ++depth;
-                    st.sp = 0;
-                    trav_begin(a.scene, org, dir, INFINITY, tr);
-                }
-            }
-            // one counter update per distinct depth among the lanes that go on
-            unsigned long long todo = __ballot(at_shade && alive);
-            while (todo != 0ull) {
-                const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)depth, (int)__builtin_ctzll(todo));
-                const unsigned long long same = __ballot(at_shade && alive && depth == d);
-                if (rank_in(~0ull) == 0u)
-                    atomicAdd(&a.counts[(size_t)(d * SEGMENTS + cur.home) * COUNTER_STRIDE], (uint32_t)__popcll(same));
-                todo &= ~same;
-            }
-        } else if (n_node >= n_leaf) {
-            if (at_node) trav_node_step(a.scene, RT_TNEAR, tr, st);
-        } else {
-            if (at_leaf) trav_leaf_step(a.scene, org, dir, RT_TNEAR, tr, st);
-        }
-    }
-}
 
 // crates/rt/src/math/stat.rs:45-52
 __device__ __forceinline__ float variance_of(float count, float sum, float sqsum) {
@@ -775,6 +700,130 @@ __device__ __forceinline__ bool channel_precise(float count, float sum, float sq
     for (int k = 1; k < 16; ++k) t = (idx == k) ? student[k] : t;
     const float err = t * sqrtf(variance_of(count, sum, sqsum));
     return err < abs_err;
+}
+
+// The thin tail of a pass: once few paths are left, a launch per bounce costs more than the bounce (the kernels are
+// latency-bound with a few hundred thousand rays: the slowest ray of a wave takes ~150 dependent steps), so this kernel
+// takes every path still alive at bounce `depth0` and runs it to its end, one path per lane: closest hit, shading, next
+// ray, in the same per-ray functions as the kernels above (results do not depend on which kernel traces a path).  Waves
+// are persistent and their lanes independent.  Traversal is extend_queue_kernel's: a lane at a leaf appends the record
+// to the wave's queue and goes on, record phases take 64 entries whatever lanes they came from.  A lane whose traversal
+// is over and whose entries have all been tested waits for a shading phase, which runs once RenderArgs::tail_shade
+// lanes wait for it (shading costs several node steps) or nothing else can run; a lane whose path has ended takes the
+// next entry of the queue of bounce depth0.  The launch lasts about as long as the deepest path while the other lanes
+// work through the short ones.  After every shading phase the wave adds its surviving lanes to the counters of the
+// bounces they enter, so the counters read like those of the wavefront kernels.
+__global__ __launch_bounds__(BLOCK) void tail_kernel(RenderArgs a, uint32_t depth0) {
+    __shared__ ExtendQueueLds lds;
+    QueueStack st = make_stack_of<QUEUE_STACK>(lds.stack, a.spill);
+    const size_t P = a.n_paths;
+    const size_t H = (size_t)SEGMENTS * a.seg_cap;
+    float *__restrict__ S = a.state;
+    const float *__restrict__ Q = a.payload[depth0 & 1u];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u);
+    WaveQueue wq{lds.queue[wave_base >> 6], 0u, 0u};
+    QueueCursor cur;
+    cur.begin(a, depth0);
+    uint32_t last_post = 0;
+    bool alive = false, exhausted = false;
+    uint32_t pid = 0, depth = depth0; // pixel and sample are recomputed from the path id when the lane is shaded
+    V3 beta = mk(0.0f, 0.0f, 0.0f);
+    float ray_depth = 0.0f;
+    Trav tr;
+    tr.cur = RT_EMPTY;
+    for (;;) {
+        if (!exhausted && (int)__popcll(__ballot(alive)) < a.refill_below) {
+            cur.claim(a, depth0);
+            uint32_t i;
+            if (cur.take(!alive, i)) {
+                const uint32_t pos = cur.seg * a.seg_cap + i;
+                const Entry e = queue_entry(a, depth0, cur.seg, i, Q + (size_t)cur.seg * a.seg_cap);
+                pid = e.pid;
+                const V3 org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+                const V3 dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
+                beta = mk(ldp(Q + 7 * H, pos), ldp(Q + 8 * H, pos), ldp(Q + 9 * H, pos));
+                ray_depth = ldp(Q + 10 * H, pos);
+                depth = depth0;
+                queued_begin(lds, a.scene, tid, org, dir, tr, st);
+                last_post = wq.head;
+                alive = true;
+            }
+            exhausted = cur.finished();
+        }
+        if (__ballot(alive) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        st.note_depth();
+        wq.post(alive, lane, tr, st, last_post);
+        const bool at_leaf = alive && tr.cur != RT_EMPTY && (tr.cur & RT_LEAF) != 0u;
+        const bool at_node = alive && tr.cur != RT_EMPTY && !at_leaf;
+        const bool at_shade = alive && tr.cur == RT_EMPTY && !wq.outstanding(last_post);
+        const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+        const uint32_t n_shade = (uint32_t)__popcll(__ballot(at_shade));
+        // with no lane at a node or a leaf, the lanes that are not ready for shading wait for queued tests
+        if (wq.length() > 0u && (wq.due(n_node, n_leaf, (uint32_t)a.queue_low) || (n_node == 0u && n_leaf == 0u && n_shade < (uint32_t)a.tail_shade))) {
+            wq.test(lds, a.scene, wave_base, lane);
+        } else if (n_shade > 0u && (n_shade >= (uint32_t)a.tail_shade || (n_node == 0u && n_leaf == 0u))) {
+            if (at_shade) {
+                float t;
+                V3 ng, org, dir;
+                uint32_t code;
+                queued_result(lds, a.scene, tid, t, ng, code, org, dir);
+                HitInfo h;
+                h.u = h.v = 0.0f;
+                h.prim_id = RT_EMPTY;
+                h.hit = code != RT_EMPTY;
+                h.t = t;
+                h.pos = mk(0.0f, 0.0f, 0.0f);
+                h.n = mk(0.0f, 0.0f, 0.0f);
+                h.geom_id = RT_EMPTY;
+                h.mat_id = 0;
+                if (h.hit) {
+                    h.pos = mk(org.x + t * dir.x, org.y + t * dir.y, org.z + t * dir.z);
+                    h.n = normalize_or_zero(ng);
+                    h.geom_id = code & RT_GEOM_MASK;
+                    h.mat_id = h.geom_id < a.scene.n_geoms ? a.scene.geom_material[h.geom_id] : 0u;
+                    if (h.mat_id >= a.scene.n_materials) h.mat_id = 0u;
+                }
+                const uint32_t per_block = a.samples * (uint32_t)PIXEL_BLOCK;
+                const uint32_t blk = pid / per_block, rem = pid - blk * per_block;
+                const uint32_t pix = blk * (uint32_t)PIXEL_BLOCK + rem % (uint32_t)PIXEL_BLOCK;
+                const uint32_t sample = a.sample_base + rem / (uint32_t)PIXEL_BLOCK;
+                VertexOut vo;
+                bool cont = shade_vertex(a.scene, h, a.integrator, a.seed, a.pixels[2 * pix], a.pixels[2 * pix + 1], sample, depth, org, dir, beta, vo);
+                if (h.hit && vo.t_add != 0.0f) ray_depth = ray_depth + vo.t_add;
+                if (cont && depth + 1u == a.max_depth) {
+                    // the next vertex would be at the depth limit: it contributes beta * 0 (pathtracing.rs:24-26)
+                    vo.radiance = mul(beta, mk(0.0f, 0.0f, 0.0f));
+                    cont = false;
+                }
+                if (!cont) {
+                    stp(S + 0 * P, pid, vo.radiance.x);
+                    stp(S + 1 * P, pid, vo.radiance.y);
+                    stp(S + 2 * P, pid, vo.radiance.z);
+                    stp(S + 13 * P, pid, ray_depth);
+                    alive = false;
+                } else {
+                    ++depth;
+                    queued_begin(lds, a.scene, tid, org, dir, tr, st);
+                    last_post = wq.head;
+                }
+            }
+            unsigned long long todo = __ballot(at_shade && alive);
+            while (todo != 0ull) {
+                const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)depth, (int)__builtin_ctzll(todo));
+                const unsigned long long same = __ballot(at_shade && alive && depth == d);
+                if (rank_in(~0ull) == 0u)
+                    atomicAdd(&a.counts[(size_t)(d * SEGMENTS + cur.home) * COUNTER_STRIDE], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        } else if (at_node) {
+            queued_node_step(lds, a.scene, tid, tr, st);
+        }
+    }
 }
 
 // RaySeries::add_sample (crates/rt/src/renderer.rs:63-82, crates/rt/src/math/stat.rs:24-28,165-168) for the `samples`
