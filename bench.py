@@ -157,10 +157,9 @@ def dry_cpu(args, rank, world):
     if rank == 0:
         want = planes * 1e6 + torch.arange(W * H, dtype=torch.float32)[None, :]
         ok = bool(torch.equal(frame, want)) and int(t_cnt[0]) == W * H and int(t_cnt[1]) == tiler.tile_count()
-        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mrays/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t_el.item()) * 1e3,
-                          "dry_cpu": True, "frame_ok": ok, "pixels": int(t_cnt[0]), "tiles": int(t_cnt[1])}))
-        sys.stdout.flush()
+        emit(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mrays/s", "n_gpus": world,
+                         "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t_el.item()) * 1e3,
+                         "dry_cpu": True, "frame_ok": ok, "pixels": int(t_cnt[0]), "tiles": int(t_cnt[1])}))
         if not ok:
             raise SystemExit("dry run: the gathered frame is wrong")
     if world > 1:
@@ -168,10 +167,33 @@ def dry_cpu(args, rank, world):
         dist.destroy_process_group()
 
 
+_result_fd = None
+
+
+def keep_stdout_for_the_result():
+    """The contract is one JSON line on stdout.  Libraries loaded here write banners of their own to file descriptor 1
+    (RCCL prints its version table when a communicator is created), so everything written to it from now on goes to
+    stderr, and emit() writes the line to what stdout was."""
+    global _result_fd
+    sys.stdout.flush()
+    _result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(line):
+    data = (line + "\n").encode()
+    if _result_fd is None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    else:
+        os.write(_result_fd, data)
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
+    keep_stdout_for_the_result()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -424,8 +446,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(json.dumps(out))
     film.close()
     if frame is not None:
         frame.close()
