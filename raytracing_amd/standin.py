@@ -8,8 +8,7 @@ midpoint-subdivided `levels` times.  The height is calibrated against the refere
 distances (0.71 / 0.78 / 0.88 at the 5th / 25th / 50th percentile) like the reference's Z channel shows (0.74 / 0.91 /
 >= 1).  So the share of camera paths that enter the glass, which is what makes this scene expensive, is the
 reference's.  Every new vertex of the subdivision is pushed off its edge by a hashed offset proportional to the edge
-length, which every new vertex is pushed off its edge by a hashed offset proportional to the edge length, which
-gives a bumpy, non-planar surface with triangles spread over all orientations.  The result depends only on the
+length, which gives a bumpy, non-planar surface with triangles spread over all orientations.  The result depends only on the
 input file and `levels`: no library random generator is involved.
 """
 from __future__ import annotations

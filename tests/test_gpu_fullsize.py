@@ -6,8 +6,10 @@ sample ranges merge) plus the oracle, bit for bit, on a strided subset of the pi
 
   Dragon 1920x1080 100 spp     the headline configuration, on the 5,087,232-triangle stand-in mesh (or obj/dragon.obj)
   Cornell box 1920x1080 5 spp  the reference's own CPU-runnable case (output/gen.sh:6)
-  Dragon 3840x2160 100 spp     more paths than one pass holds: the multi-pass driver at full pixel count
-  Cornell box 3840x2160        at 64 of its 1000 spp (the strata grid stays that of 1000 spp)
+  Dragon 3840x2160 100 spp     more paths than one pass holds: the multi-pass driver at full pixel count; the scene as
+                               the reference builds it (rough glass, dragon.rs:17-46) and with the mesh diffuse
+  Cornell box 3840x2160        all 1000 spp (strata 31 x 31 + 39 wrapped samples), as output/gen.sh:6 runs a
+                               configuration: the full sample count, not a prefix
 """
 import numpy as np
 import pytest
@@ -187,20 +189,79 @@ def test_dragon_4k_100spp_in_several_passes(oracle, dragon, device):
     film.close()
 
 
-def test_cornell_4k_strata_of_1000spp(oracle, cornell, device):
-    """Cornell box 3840x2160 on the 31 x 31 strata grid of the 1000-spp configuration, samples 0..64 (the full 1000
-    take 7 s; every sample is independent of how many follow)."""
-    from raytracing_amd import types
+@pytest.fixture(scope="module")
+def dragon_diffuse(oracle, scene_classes, device):
+    """The dragon scene with the mesh given the sphere's kind of material (a diffuse BxDF): the "multi-bounce diffuse"
+    variant of the 3840x2160 configuration."""
+    from raytracing_amd import api
+    sg = api.HipScene(device)
+    scene_classes["dragon"].insert_into(sg, diffuse=True)
+    world = sg.commit().into_world()
+    so = oracle.OracleScene()
+    scene_classes["dragon"].insert_into(so, diffuse=True)
+    so.commit()
+    yield so, world
+    sg.close()
+
+
+def test_dragon_diffuse_4k_100spp(oracle, dragon_diffuse, device):
+    """Dragon 3840x2160, 100 spp, every surface diffuse: 829 M camera paths in several passes."""
+    from raytracing_amd import api, types
+    so, world = dragon_diffuse
+    W, H, spp = 3840, 2160, 100
+    cam = types.Camera.from_dimensions(W, H)
+    xy, whole, st = render_frame(world, device, cam, spp)
+    assert st["paths"] == W * H * spp and st["passes"] >= 2
+    assert st["rays"] > int(1.3 * st["paths"])  # diffuse inter-reflection: more than the camera ray and one bounce
+    assert (whole[21] == spp).all() and (whole[9] == spp).all()
+    # determinism
+    _, again, st2 = render_frame(world, device, cam, spp)
+    assert st2["rays"] == st["rays"] and same_bits(again, whole).all()
+    del again
+    check_subset_against_oracle(oracle, so, world, device, cam, spp, xy, whole, 16001)
+    # the same frame as two sample ranges (RaySeries::merge, renderer.rs:84-95)
+    film = api.Film(device, xy)
+    a = api.render(world, film, cam, spp, range(0, 63))
+    b = api.render(world, film, cam, spp, range(63, 100))
+    assert a["rays"] + b["rays"] == st["rays"]
+    assert same_bits(film.download(), whole).all()
+    film.close()
+    # interleaved tile halves (what two ranks would render) reassemble the frame
+    n_tiles = 120 * 68
+    parts = [render_frame(world, device, cam, spp, tiles=range(r, n_tiles, 2)) for r in range(2)]
+    assert parts[0][2]["rays"] + parts[1][2]["rays"] == st["rays"]
+    pxy = np.concatenate([p[0] for p in parts], 0)
+    pacc = np.concatenate([p[1] for p in parts], 1)
+    assert same_bits(pacc[:, frame_order(pxy, W)], whole[:, frame_order(xy, W)]).all()
+
+
+def test_cornell_4k_1000spp(oracle, cornell, device):
+    """Cornell box 3840x2160 at the full 1000 spp: 8.3 G camera paths, 72 G rays, in passes of at most 2^30 queue
+    entries.  f32 sums over 1000 samples per pixel and counts up to 1000 are part of what is compared."""
+    from raytracing_amd import api, types
     so, world = cornell
     W, H, spp = 3840, 2160, 1000
     cam = types.Camera.from_dimensions(W, H)
-    xy, whole, st = render_frame(world, device, cam, spp, sample_range=range(0, 64))
-    assert st["paths"] == W * H * 64 and (whole[21] == 64).all()
-    assert st["rays"] > 8 * st["paths"]
-    check_subset_against_oracle(oracle, so, world, device, cam, spp, xy, whole, 16001, sample_range=range(0, 64))
-    # samples 990..1000, the wrapped strata (1000 = 31 * 31 + 39): a different range gives different, valid samples
+    xy, whole, st = render_frame(world, device, cam, spp)
+    assert st["paths"] == W * H * spp and st["passes"] >= 8
+    assert (whole[21] == spp).all() and (whole[9] == spp).all()
+    assert st["rays"] > 8 * st["paths"] and st["max_bounces"] >= 60
+    # determinism
+    _, again, st2 = render_frame(world, device, cam, spp)
+    assert st2["rays"] == st["rays"] and same_bits(again, whole).all()
+    del again
+    # ~520 pixels x 1000 samples against the oracle, bit for bit, with equal ray counts
+    check_subset_against_oracle(oracle, so, world, device, cam, spp, xy, whole, 16001)
+    # two sample ranges accumulate to the same frame (RaySeries::merge, renderer.rs:84-95); the second starts inside
+    # the wrapped strata (961 = 31 * 31)
+    film = api.Film(device, xy)
+    a = api.render(world, film, cam, spp, range(0, 970))
+    b = api.render(world, film, cam, spp, range(970, 1000))
+    assert a["rays"] + b["rays"] == st["rays"]
+    assert same_bits(film.download(), whole).all()
+    film.close()
+    # samples 990..1000 on their own: a different range gives different, valid samples
     sub = np.arange(0, xy.shape[0], 8009)
-    from raytracing_amd import api
     film = api.Film(device, xy[sub])
     api.render(world, film, cam, spp, range(990, 1000))
     want, _ = so.render(cam, oracle.make_params(spp=spp, sample_begin=990, sample_end=1000), xy[sub])

@@ -1,9 +1,11 @@
 """The HIP path's images against the renders the reference itself holds (output/{cornell5,cornell20,cornell100,
-dragon100}/*.jpeg, 1920x1080, sRGB-encoded 8-bit JPEG, produced by output/gen.sh:1-11; copied to tests/golden/).
+dragon5,dragon20,dragon100}/*.jpeg, 1920x1080, sRGB-encoded 8-bit JPEG, produced by output/gen.sh:1-11; copied to
+tests/golden/).
 
 Cornell: converged and unconverged colour at the reference's three sample counts, compared at the level of its 32x32
 tiles, and the first-hit channels pixel by pixel.  Dragon: the mesh the reference rendered is not distributed, but its
-renders still pin this scene's camera, sky and diffuse sphere wherever the dragon does not cover them.
+renders still pin this scene's camera, sky and diffuse sphere wherever the dragon does not cover them, and -- coarsely,
+because the mesh differs -- the converged colour of the sphere and the mean colour of the glass.
 """
 import os
 
@@ -85,7 +87,35 @@ def srgb(linear):
     return np.where(linear < 0.0031308, 12.92 * linear, 1.055 * linear ** (1 / 2.4) - 0.055)
 
 
-def test_dragon_scene_against_the_reference_render(scene_classes, device):
+@pytest.fixture(scope="module")
+def dragon_world(scene_classes, device):
+    from raytracing_amd import api
+    sg = api.HipScene(device)
+    scene_classes["dragon"].insert_into(sg)
+    world = sg.commit().into_world()
+    world.mesh_name = getattr(sg, "dragon_mesh", "")
+    yield world
+    sg.close()
+
+
+SPHERE_ALBEDO = srgb(np.array([0.2, 0.1, 0.5]) / np.pi) * 255.0  # dragon.rs:40-46, albedo = f = Kd / pi
+
+
+def dragon_masks(img255, golden=False):
+    """sky / sphere / mesh masks of a first-hit image ([15, H, W] scaled to 0..255), or of the reference's
+    output/dragon100 channels (8-bit JPEG: looser thresholds)."""
+    if golden:
+        g_alb, g_z = load_golden("dragon100/Albedo"), load_golden("dragon100/Z", "L")
+        sky = (g_alb.max(-1) <= 6) & (g_z <= 3)
+        sph = np.abs(g_alb - SPHERE_ALBEDO).max(-1) <= 8
+    else:
+        alb = np.moveaxis(img255[6:9], 0, -1)
+        sky = (alb.max(-1) == 0) & (img255[13] == 0)
+        sph = np.abs(alb - SPHERE_ALBEDO).max(-1) <= 1.0
+    return sky, sph, ~sky & ~sph
+
+
+def test_dragon_scene_against_the_reference_render(dragon_world, device):
     """output/dragon100/{Albedo,Normal,Position,Z,Color}.jpeg.  The reference's dragon mesh is absent, so this scene is
     rendered with the stand-in mesh; the pixels that show sky or the diffuse sphere (-0.7, -0.2, -1.9) r 0.8, albedo
     (0.2, 0.1, 0.5) (crates/rt/src/scene/examples/dragon.rs:40-46) in BOTH images do not depend on the mesh:
@@ -94,25 +124,18 @@ def test_dragon_scene_against_the_reference_render(scene_classes, device):
     - sky pixels carry the constant sky colour sRGB(0.5, 0.3, 1.0) = (186, 149, 254) in the reference's Color.
     The share of the frame the stand-in covers is compared with the reference's dragon (33.8 %): that share is the
     share of camera paths that enter the glass, i.e. what this workload costs."""
-    from raytracing_amd import api
-    sg = api.HipScene(device)
-    scene_classes["dragon"].insert_into(sg)
-    world = sg.commit().into_world()
+    world = dragon_world
     img = gpu_image(world, device, 100, max_depth=1, sample_range=range(0, 16)) * 255.0
-    sg.close()
     g_alb, g_nor, g_pos = (load_golden("dragon100/" + n) for n in ("Albedo", "Normal", "Position"))
-    g_z, g_col = load_golden("dragon100/Z", "L"), load_golden("dragon100/Color")
-    sphere_albedo = srgb(np.array([0.2, 0.1, 0.5]) / np.pi) * 255.0
-    g_sky = (g_alb.max(-1) <= 6) & (g_z <= 3)
-    g_sph = np.abs(g_alb - sphere_albedo).max(-1) <= 8
+    g_col = load_golden("dragon100/Color")
+    g_sky, g_sph, g_mesh = dragon_masks(None, golden=True)
     o_alb, o_nor, o_pos = (np.moveaxis(img[p], 0, -1) for p in (slice(6, 9), slice(0, 3), slice(3, 6)))
-    o_sky = (o_alb.max(-1) == 0) & (img[13] == 0)
-    o_sph = np.abs(o_alb - sphere_albedo).max(-1) <= 1.0
-    ours_cover, ref_cover = float((~o_sky & ~o_sph).mean()), float((~g_sky & ~g_sph).mean())
+    o_sky, o_sph, o_mesh = dragon_masks(img)
+    ours_cover, ref_cover = float(o_mesh.mean()), float(g_mesh.mean())
     print("dragon: mesh covers %.1f %% of the frame (reference %.1f %%), sky %.1f %% (reference %.1f %%)"
           % (100 * ours_cover, 100 * ref_cover, 100 * o_sky.mean(), 100 * g_sky.mean()))
     assert abs(g_sky.mean() - 0.575) < 0.005 and abs(ref_cover - 0.338) < 0.005  # what the fixture holds
-    if "stand-in" in getattr(sg, "dragon_mesh", ""):
+    if "stand-in" in world.mesh_name:
         assert abs(ours_cover - ref_cover) < 0.02
     free = (g_sky | g_sph) & (o_sky | o_sph)  # neither image shows its dragon here
     assert free.mean() > 0.4
@@ -124,5 +147,50 @@ def test_dragon_scene_against_the_reference_render(scene_classes, device):
         assert d.mean() < 2.0 and (d > 8).mean() < 0.02, (name, d.mean(), (d > 8).mean())
     sky_both = g_sky & o_sky
     assert np.abs(g_col[sky_both].mean(0) - np.array([186.0, 149.0, 254.0])).max() < 2.0
-    # and the GPU's own colour there, at full depth, is that constant exactly (to the 8-bit step)
-    assert np.abs(np.round(srgb([0.5, 0.3, 1.0]) * 255) - np.array([188.0, 149.0, 255.0])).max() <= 2
+    # and the GPU's own colour there, at full depth: sRGB(0.5, 0.3, 1.0) to the 8-bit step on every pixel none of whose
+    # samples (box filter radius 0.7: up to 0.2 pixels outside) can reach the mesh or the sphere
+    full = gpu_image(world, device, 4) * 255.0
+    far_sky = o_sky.copy()
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            far_sky &= np.roll(np.roll(o_sky, dy, 0), dx, 1)
+    col = np.moveaxis(full[9:12], 0, -1)[far_sky]
+    assert col.shape[0] > 0.5 * W * H
+    assert np.abs(col - srgb([0.5, 0.3, 1.0]) * 255.0).max() <= 1.0
+
+
+@pytest.mark.parametrize("spp", [5, 20, 100])
+def test_dragon_colour_coarse_pins(dragon_world, device, spp):
+    """output/dragon{5,20,100}/Color.jpeg against the GPU's frame at the same sample count.  Coarse by necessity: the
+    reference's mesh is not distributed, the stand-in is a different shape with the same material, transform and frame
+    coverage.  Two things survive that:
+    - the converged colour of the diffuse sphere (lit by the sky and, second order, by light leaving the glass):
+      32x32-tile means over the sphere's pixels within 0.035 RMSE of the reference's and the mean colour within 0.03 per
+      channel (measured: 0.020 and 0.014; the seed-to-seed floor is 0.005 / 0.002 / 0.001 at 5 / 20 / 100 spp, the rest
+      is the different mesh next to it);
+    - the mean sRGB colour of the glass (rough dielectric, ior 1.5, roughness 0.2, dragon.rs:19-22;
+      material/mod.rs:272-311) over each image's own mesh-covered pixels: every channel within 20 % of the reference's
+      (measured: 0.90 / 0.875 / 0.92 of it).  A wrong Fresnel split, a lost refraction branch or an f / pdf that gains or
+      loses energy shows up as a multiple, not as 10 %.
+    Everything else that depends on the mesh stays unpinned."""
+    first = gpu_image(dragon_world, device, 100, max_depth=1, sample_range=range(0, 16)) * 255.0
+    img = gpu_image(dragon_world, device, spp)
+    o_sky, o_sph, o_mesh = dragon_masks(first)
+    g_sky, g_sph, g_mesh = dragon_masks(None, golden=True)
+    ours = np.moveaxis(img[9:12], 0, -1)
+    gold = load_golden("dragon%d/Color" % spp) / 255.0
+    both = g_sph & o_sph
+    n = both[:1056].reshape(33, 32, 60, 32).sum((1, 3))
+    tiles = n >= 512
+
+    def tile_means(c):
+        return (c[:1056] * both[:1056, :, None]).reshape(33, 32, 60, 32, 3).sum((1, 3))[tiles] / n[tiles][:, None]
+    rmse = float(np.sqrt(((tile_means(ours) - tile_means(gold)) ** 2).mean()))
+    d_mean = np.abs(ours[both].mean(0) - gold[both].mean(0))
+    ratio = ours[o_mesh].mean(0) / gold[g_mesh].mean(0)
+    print("dragon %d spp: sphere tile RMSE %.4f over %d tiles, mean colour off by %s; glass mean sRGB ours / reference %s"
+          % (spp, rmse, int(tiles.sum()), d_mean, ratio))
+    assert tiles.sum() >= 40
+    assert rmse < 0.035 and d_mean.max() < 0.03
+    if "stand-in" in dragon_world.mesh_name:
+        assert (ratio > 0.8).all() and (ratio < 1.2).all()
