@@ -307,12 +307,19 @@ void rtmi_comm_destroy(rtmi_comm *comm);
  * used on the root only (a film made by rtmi_film_create_frame on the root's device; NULL elsewhere) and pixels no
  * rank sent keep their old values.  Nothing is reduced: ranks must own disjoint pixels.  comm == NULL is the
  * single-GPU case (film and frame on one device).  The first call for a (film, comm, root) combination also sends
- * the pixel lists to the root; later calls move only the 88 bytes per pixel, each peer straight to the root, after a
- * 16-byte status exchange in which the ranks tell each other whether they can take part: if one of them cannot (a bad
- * argument, a film with pixels outside the frame, no memory for the root's staging), every rank returns an error
- * (the failing rank its own, the others RTMI_ERR_STATE) and nothing has been exchanged.  The root may gather into a
- * different frame from call to call.  Synchronous: returns when the frame is complete on the root. */
+ * the pixel lists to the root; later calls move only the 88 bytes per pixel, each peer straight to the root (the root's
+ * own pixels go from its film into the frame directly), after a 32-byte status exchange in which the ranks tell each
+ * other which film they bring and whether they can take part.  Any rank may bring a different film from call to call:
+ * the lists travel again whenever the set of films differs from the one a rank's plan was made for.  If a rank cannot
+ * take part (a bad argument, a film with pixels outside the frame, no memory for the root's staging), every rank
+ * returns an error (the failing rank its own, the others RTMI_ERR_STATE) and nothing has been exchanged.  The root may
+ * gather into a different frame from call to call.  Synchronous: returns when the frame is complete on the root. */
 int rtmi_film_gather(rtmi_film *film, rtmi_comm *comm, int root, rtmi_film *frame);
+/* For a rank that cannot call rtmi_film_gather this frame (its render failed, it has no film): takes the rank's place
+ * in the collective and tells the peers, which then return RTMI_ERR_STATE from their rtmi_film_gather instead of
+ * waiting for this rank.  The reference has no counterpart (a panicking rayon worker aborts the whole process,
+ * executor.rs:313-329). */
+int rtmi_comm_gather_abort(rtmi_comm *comm);
 
 #ifdef __cplusplus
 }

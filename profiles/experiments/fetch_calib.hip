@@ -4,15 +4,19 @@
 //
 //   stream_read     16 bytes per lane, consecutive lanes on consecutive addresses, 4 GiB once through
 //   stream_write    the same as stores, 1 GiB
-//   gather<64>      every lane loads one 64-byte record (four 16-byte loads) at a hashed position of a 4 GiB table:
+//   gather<64>      every lane loads one 64-byte record (four 16-byte loads) at a hashed position of a 512 MiB table
+//                   (twice the Infinity Cache; hashed over 4 GiB the same loads run at 0.4 of the rate, bound by
+//                   address translation, which a scene of a few hundred MB is not):
 //                   the pattern of a BVH node or primitive record fetch that misses every cache
 //   gather<128>     every lane loads one 128-byte record (eight loads), 128-byte aligned
 //   gather_pair     every lane loads the two 64-byte halves of one hashed 128-byte line as two separate records
 //                   (what a layout that pairs items fetched together would do)
 //
-// It also times gather<64> on a stream restricted to half of the CUs (hipExtStreamCreateWithCUMask): if the rate of
-// scattered line fetches is a property of the fabric / memory the time does not change, if it is a property of each
-// CU's L1 miss path the time doubles.
+// `fetch_calib 1` also times the gathers with 32 .. 512 blocks of 1024 threads (sixteen waves, one block per CU while
+// there are fewer blocks than CUs): if the rate of scattered line fetches is a property of the fabric / memory the
+// rate stops growing before all CUs are in use, if it is a property of each CU's L1 miss path it grows with the CUs.
+// (A stream restricted to a subset of the CUs with hipExtStreamCreateWithCUMask would say the same more directly;
+// creating one with a partial mask crashed the process on the machines this ran on.)
 //
 //   hipcc --offload-arch=gfx950 -O3 -o fetch_calib fetch_calib.hip
 #include <hip/hip_runtime.h>
@@ -49,18 +53,18 @@ __global__ __launch_bounds__(256) void stream_write(F4 *__restrict__ buf, size_t
 
 // BYTES = 64 or 128: one record per lane and iteration at a hashed, BYTES-aligned position.
 template <int BYTES>
-__global__ __launch_bounds__(256) void gather(const F4 *__restrict__ buf, uint32_t mask64, int iters, float *out) {
-    uint32_t h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+__global__ __launch_bounds__(1024) void gather(const F4 *__restrict__ buf, uint32_t mask64, int iters, float *out) {
+    uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
     float acc = 0.0f;
     for (int i = 0; i < iters; ++i) {
         h = h * 1664525u + 1013904223u;
-        uint32_t rec = (h >> 6) & mask64; // index of a 64-byte record
+        uint32_t rec = (h >> 9) & mask64; // index of a 64-byte record
         if (BYTES == 128) rec &= ~1u;
         const F4 *p = buf + (size_t)rec * 4;
 #pragma unroll
         for (int k = 0; k < BYTES / 16; ++k) {
             const F4 v = p[k];
-            acc += v.x + v.w;
+            acc += v.x + v.y + v.z + v.w; // all four words, so that the load stays a 16-byte one
         }
     }
     if (acc == 123.456f) out[0] = acc;
@@ -72,13 +76,19 @@ __global__ __launch_bounds__(256) void gather_pair(const F4 *__restrict__ buf, u
     float acc = 0.0f;
     for (int i = 0; i < iters; ++i) {
         h = h * 1664525u + 1013904223u;
-        const uint32_t rec = (h >> 6) & mask64;
+        const uint32_t rec = (h >> 9) & mask64;
         const F4 *p = buf + (size_t)rec * 4;
         const F4 *q = buf + (size_t)(rec ^ 1u) * 4;
-        const F4 a = p[0], b = p[1], c = p[2], d = p[3];
-        acc += a.x + b.y + c.z + d.w;
-        const F4 e = q[0], f = q[1], g = q[2], hh = q[3];
-        acc += e.x + f.y + g.z + hh.w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const F4 v = p[k];
+            acc += v.x + v.y + v.z + v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const F4 v = q[k];
+            acc += v.x + v.y + v.z + v.w;
+        }
     }
     if (acc == 123.456f) out[0] = acc;
 }
@@ -101,11 +111,13 @@ static float timed(hipStream_t s, void (*launch)(hipStream_t)) {
 
 static F4 *g_buf;
 static float *g_out;
-static const uint32_t RECORDS = 1u << 26; // 64-byte records in the 4 GiB table
+static const uint32_t RECORDS = 1u << 26; // 64-byte records in the 4 GiB buffer the streaming kernels run over
+static const uint32_t TABLE = 1u << 23;   // 64-byte records of the 512 MiB the gathers hash into
 static const int BLOCKS = 256 * 6, ITERS = 256;
 
 int main(int argc, char **argv) {
-    const bool cu_mask_part = argc > 1 && atoi(argv[1]) != 0;
+    const int extra = argc > 1 ? atoi(argv[1]) : 0;
+    setvbuf(stdout, nullptr, _IONBF, 0);
     CHECK(hipMalloc(&g_buf, (size_t)RECORDS * 64));
     CHECK(hipMemset(g_buf, 0, (size_t)RECORDS * 64));
     CHECK(hipMalloc(&g_out, 4096));
@@ -117,36 +129,22 @@ int main(int argc, char **argv) {
     printf("stream_read    bytes %.0f  %.3f ms  %.0f GB/s\n", (double)RECORDS * 64, ms, (double)RECORDS * 64 / ms / 1e6);
     ms = timed(0, [](hipStream_t s) { hipLaunchKernelGGL(stream_write, dim3(256 * 16), dim3(256), 0, s, g_buf, (size_t)RECORDS); });
     printf("stream_write   bytes %.0f  %.3f ms  %.0f GB/s\n", (double)RECORDS * 16, ms, (double)RECORDS * 16 / ms / 1e6);
-    ms = timed(0, [](hipStream_t s) { hipLaunchKernelGGL(gather<64>, dim3(BLOCKS), dim3(256), 0, s, g_buf, RECORDS - 1, ITERS, g_out); });
+    ms = timed(0, [](hipStream_t s) { hipLaunchKernelGGL(gather<64>, dim3(BLOCKS), dim3(256), 0, s, g_buf, TABLE - 1, ITERS, g_out); });
     printf("gather<64>     records %.0f useful bytes %.0f  %.3f ms  %.2f G records/s  %.0f GB/s useful\n", recs, recs * 64, ms, recs / ms / 1e6, recs * 64 / ms / 1e6);
-    ms = timed(0, [](hipStream_t s) { hipLaunchKernelGGL(gather<128>, dim3(BLOCKS), dim3(256), 0, s, g_buf, RECORDS - 1, ITERS, g_out); });
+    ms = timed(0, [](hipStream_t s) { hipLaunchKernelGGL(gather<128>, dim3(BLOCKS), dim3(256), 0, s, g_buf, TABLE - 1, ITERS, g_out); });
     printf("gather<128>    records %.0f useful bytes %.0f  %.3f ms  %.2f G records/s  %.0f GB/s useful\n", recs, recs * 128, ms, recs / ms / 1e6, recs * 128 / ms / 1e6);
-    ms = timed(0, [](hipStream_t s) { hipLaunchKernelGGL(gather_pair, dim3(BLOCKS), dim3(256), 0, s, g_buf, RECORDS - 1, ITERS, g_out); });
+    ms = timed(0, [](hipStream_t s) { hipLaunchKernelGGL(gather_pair, dim3(BLOCKS), dim3(256), 0, s, g_buf, TABLE - 1, ITERS, g_out); });
     printf("gather_pair    lines %.0f useful bytes %.0f  %.3f ms  %.2f G lines/s  %.0f GB/s useful\n", recs, recs * 128, ms, recs / ms / 1e6, recs * 128 / ms / 1e6);
 
-    if (cu_mask_part) {
-        // all CUs against every other CU: a stream whose CU mask has every second bit set
-        hipDeviceProp_t prop;
-        CHECK(hipGetDeviceProperties(&prop, 0));
-        const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
-        uint32_t all[16] = {0}, half[16] = {0}, quarter[16] = {0};
-        for (int c = 0; c < n_cu; ++c) {
-            all[c / 32] |= 1u << (c % 32);
-            if (c % 2 == 0) half[c / 32] |= 1u << (c % 32);
-            if (c % 4 == 0) quarter[c / 32] |= 1u << (c % 32);
-        }
-        const struct {
-            const char *name;
-            const uint32_t *mask;
-        } sets[] = {{"all CUs", all}, {"every 2nd CU", half}, {"every 4th CU", quarter}};
-        for (const auto &st : sets) {
-            hipStream_t s;
-            CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, st.mask));
-            ms = timed(s, [](hipStream_t q) { hipLaunchKernelGGL(gather<64>, dim3(BLOCKS), dim3(256), 0, q, g_buf, RECORDS - 1, ITERS, g_out); });
-            printf("gather<64> on %-13s (%d CUs in the device)  %.3f ms  %.2f G records/s\n", st.name, n_cu, ms, recs / ms / 1e6);
-            ms = timed(s, [](hipStream_t q) { hipLaunchKernelGGL(gather<128>, dim3(BLOCKS), dim3(256), 0, q, g_buf, RECORDS - 1, ITERS, g_out); });
-            printf("gather<128> on %-13s  %.3f ms  %.2f G records/s\n", st.name, ms, recs / ms / 1e6);
-            CHECK(hipStreamDestroy(s));
+    if (extra == 1) {
+        static int n_blocks;
+        for (int nb : {32, 64, 128, 192, 256, 512}) {
+            n_blocks = nb;
+            const double r = (double)nb * 1024.0 * ITERS;
+            ms = timed(0, [](hipStream_t s) { hipLaunchKernelGGL(gather<64>, dim3(n_blocks), dim3(1024), 0, s, g_buf, TABLE - 1, ITERS, g_out); });
+            printf("gather<64>  %3d blocks of 1024 threads  %.3f ms  %.2f G records/s\n", nb, ms, r / ms / 1e6);
+            ms = timed(0, [](hipStream_t s) { hipLaunchKernelGGL(gather<128>, dim3(n_blocks), dim3(1024), 0, s, g_buf, TABLE - 1, ITERS, g_out); });
+            printf("gather<128> %3d blocks of 1024 threads  %.3f ms  %.2f G records/s\n", nb, ms, r / ms / 1e6);
         }
     }
     CHECK(hipDeviceSynchronize());

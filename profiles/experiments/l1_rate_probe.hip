@@ -17,11 +17,16 @@ __global__ __launch_bounds__(256) void probe(const F4 *__restrict__ buf, unsigne
     const unsigned lane = threadIdx.x & 63u;
     for (int i = 0; i < iters; ++i) {
         h = h * 1664525u + 1013904223u;
-        if (MODE == 0) { // one record per lane, four loads
+        if (MODE == 0) { // one record per lane, four 16-byte loads (every word is used: reading one word of each
+                         // quarter lets the compiler shrink the loads to four 4-byte ones, which is MODE 6)
+            const F4 *p = buf + (size_t)((h >> 8) & mask) * 4;
+            F4 a = p[0], b = p[1], c = p[2], d = p[3];
+            acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+            if (DEP) h += __float_as_uint(a.x) + __float_as_uint(d.w); // the buffer holds zeros: same sequence, real dependency
+        } else if (MODE == 6) { // one record per lane, one word of each quarter: four 4-byte loads
             const F4 *p = buf + (size_t)((h >> 8) & mask) * 4;
             F4 a = p[0], b = p[1], c = p[2], d = p[3];
             acc += a.x + b.y + c.z + d.w;
-            if (DEP) h += __float_as_uint(a.x) + __float_as_uint(d.w); // the buffer holds zeros: same sequence, real dependency
         } else if (MODE == 2) { // as MODE 1, then through LDS so that every lane ends up with its own whole record
             const unsigned wave_base = (threadIdx.x & ~63u);
 #pragma unroll
@@ -74,9 +79,9 @@ int main() {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int iters = 2000;
-    struct { const char *name; unsigned records; } sizes[] = {{"8 KB (L1)", 128}, {"1 MB (L2)", 16384}, {"64 MB (MALL)", 1u << 20}, {"512 MB (HBM)", 1u << 23}, {"4 GB (HBM)", 1u << 26}};
+    struct { const char *name; unsigned records; } sizes[] = {{"8 KB (L1)", 128}, {"1 MB (L2)", 16384}, {"64 MB (MALL)", 1u << 20}, {"256 MB", 1u << 22}, {"512 MB (HBM)", 1u << 23}, {"4 GB (HBM)", 1u << 26}};
     for (auto &s : sizes)
-        for (int mode = 0; mode < 6; ++mode) {
+        for (int mode = 0; mode < 7; ++mode) {
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0, 0);
                 if (mode == 0) hipLaunchKernelGGL((probe<0, false>), dim3(blocks), dim3(256), 0, 0, buf, s.records - 1, iters, out);
@@ -84,7 +89,8 @@ int main() {
                 else if (mode == 2) hipLaunchKernelGGL((probe<2, false>), dim3(blocks), dim3(256), 0, 0, buf, s.records - 1, iters, out);
                 else if (mode == 3) hipLaunchKernelGGL((probe<0, true>), dim3(blocks), dim3(256), 0, 0, buf, s.records - 1, iters, out);
                 else if (mode == 4) hipLaunchKernelGGL((probe<2, true>), dim3(blocks), dim3(256), 0, 0, buf, s.records - 1, iters, out);
-                else hipLaunchKernelGGL((probe<5, false>), dim3(blocks), dim3(256), 0, 0, buf, s.records - 1, iters, out);
+                else if (mode == 5) hipLaunchKernelGGL((probe<5, false>), dim3(blocks), dim3(256), 0, 0, buf, s.records - 1, iters, out);
+                else hipLaunchKernelGGL((probe<6, false>), dim3(blocks), dim3(256), 0, 0, buf, s.records - 1, iters, out);
                 hipEventRecord(e1, 0);
                 hipEventSynchronize(e1);
             }
@@ -94,7 +100,7 @@ int main() {
             const double rec_per_cu = 6.0 * 256.0 * iters;
             const double ns_per_rec = ms * 1e6 / rec_per_cu;
             printf("%-14s %-22s %8.3f ms  %6.3f ns per 64-B record per CU  (%.2f records per clock at 2.4 GHz, %.0f GB/s per GPU)\n", s.name,
-                   mode == 0 ? "4 loads per lane" : mode == 1 ? "1 load per lane, quads" : mode == 2 ? "quads + LDS transpose" : mode == 3 ? "4 loads/lane, dependent" : mode == 4 ? "quads + LDS, dependent" : "8 lanes per 128-B line", ms, ns_per_rec, 1.0 / (ns_per_rec * 2.4),
+                   mode == 0 ? "4 loads per lane" : mode == 1 ? "1 load per lane, quads" : mode == 2 ? "quads + LDS transpose" : mode == 3 ? "4 loads/lane, dependent" : mode == 4 ? "quads + LDS, dependent" : mode == 5 ? "8 lanes per 128-B line" : "4 x 4-byte loads per lane", ms, ns_per_rec, 1.0 / (ns_per_rec * 2.4),
                    rec_per_cu * 256.0 * 64.0 / (ms * 1e-3) / 1e9);
         }
     return 0;

@@ -97,6 +97,7 @@ SIGNATURES = {
     "rtmi_film_pixel_count": (_sz, [_vp]),
     "rtmi_film_pixels": (C.c_int, [_vp, _vp]),
     "rtmi_film_gather": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "rtmi_comm_gather_abort": (C.c_int, [_vp]),
     "rtmi_comm_unique_id": (C.c_int, [C.c_char_p]),
     "rtmi_comm_create": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "rtmi_comm_destroy": (None, [_vp]),

@@ -308,6 +308,11 @@ class Comm:
         check(self._l.rtmi_comm_create(device._h, unique_id, self.rank, self.world, C.byref(h)))
         self._h = h
 
+    def gather_abort(self):
+        """rtmi_comm_gather_abort: this rank's turn in a frame's gather when it has nothing to bring (its render failed);
+        the peers' Film.gather then raises instead of waiting."""
+        check(self._l.rtmi_comm_gather_abort(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             self._l.rtmi_comm_destroy(self._h)

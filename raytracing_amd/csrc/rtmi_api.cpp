@@ -567,6 +567,8 @@ int rtmi_film_create(rtmi_device *dev, const uint32_t *xy, size_t n_pixels, floa
     USE_DEVICE(dev);
     rtmi_film *f = new rtmi_film();
     f->dev = dev;
+    static std::atomic<unsigned long long> next_film_id{1};
+    f->id = next_film_id.fetch_add(1);
     f->n_pixels = n_pixels;
     const size_t xy_bytes = std::max<size_t>(1, n_pixels) * 2 * sizeof(uint32_t);
     hipError_t e = hipMalloc((void **)&f->d_xy, xy_bytes);

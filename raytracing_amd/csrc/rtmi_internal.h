@@ -142,6 +142,7 @@ struct rtmi_scene {
 
 struct rtmi_film {
     rtmi_device *dev = nullptr;
+    unsigned long long id = 0; // unique among the films this process has made; tells a gather's peers which film a rank brings
     size_t n_pixels = 0;
     uint32_t *d_xy = nullptr;
     float *d_accum = nullptr;

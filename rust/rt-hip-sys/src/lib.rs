@@ -66,6 +66,7 @@ extern "C" {
     pub fn rtmi_comm_create(dev: *mut RtmiDevice, id: *const u8, rank: c_int, world: c_int, out: *mut *mut RtmiComm) -> c_int;
     pub fn rtmi_comm_destroy(comm: *mut RtmiComm);
     pub fn rtmi_film_gather(film: *mut RtmiFilm, comm: *mut RtmiComm, root: c_int, frame: *mut RtmiFilm) -> c_int;
+    pub fn rtmi_comm_gather_abort(comm: *mut RtmiComm) -> c_int;
     pub fn rtmi_render(scene: *mut RtmiScene, film: *mut RtmiFilm, camera: *const RtmiCamera, params: *const RtmiRenderParams, stats: *mut RtmiRenderStats) -> c_int;
 }
 
@@ -214,22 +215,31 @@ pub fn run_hip_rank(scene: &CommittedHipScene, camera: &RtmiCamera, params: &Rtm
     let (w, h) = (camera.width, camera.height);
     let fail = |what: &str| anyhow::anyhow!("{what}: {}", last_error());
     unsafe {
+        // Without a communicator there is nothing to leave in step with; every later failure must still take this
+        // rank's turn in the gather (rtmi_comm_gather_abort), or the peers would wait for it.
         let mut comm = std::ptr::null_mut();
         if world > 1 && rtmi_comm_create(dev, id.as_ptr(), rank, world, &mut comm) != 0 { return Err(fail("rtmi_comm_create")); }
         let mut film = std::ptr::null_mut();
-        if rtmi_film_create_tiles(dev, 0, 0, w, h, tile_size, rank as u32, world as u32, 8, 8, &mut film) != 0 { return Err(fail("rtmi_film_create_tiles")); }
         let mut frame = std::ptr::null_mut();
-        if rank == 0 && rtmi_film_create_frame(dev, 0, 0, w, h, &mut frame) != 0 { return Err(fail("rtmi_film_create_frame")); }
-        let mut stats = RtmiRenderStats::default();
-        let mut rc = rtmi_render(scene.scene.raw, film, camera, params, &mut stats);
-        if rc == 0 { rc = rtmi_film_gather(film, comm, 0, frame); }
-        let mut out = Vec::new();
-        if rc == 0 && rank == 0 {
-            out = vec![0f32; 15 * (w as usize) * (h as usize)];
-            rc = rtmi_film_resolve(frame, out.as_mut_ptr(), 0);
+        let mut err = None;
+        if rtmi_film_create_tiles(dev, 0, 0, w, h, tile_size, rank as u32, world as u32, 8, 8, &mut film) != 0 {
+            err = Some(fail("rtmi_film_create_tiles"));
+        } else if rank == 0 && rtmi_film_create_frame(dev, 0, 0, w, h, &mut frame) != 0 {
+            err = Some(fail("rtmi_film_create_frame"));
+        } else {
+            let mut stats = RtmiRenderStats::default();
+            if rtmi_render(scene.scene.raw, film, camera, params, &mut stats) != 0 { err = Some(fail("rtmi_render")); }
         }
-        let err = if rc != 0 { Some(fail("run_hip_rank")) } else { None };
-        rtmi_film_destroy(film);
+        let mut out = Vec::new();
+        if err.is_some() {
+            if !comm.is_null() { rtmi_comm_gather_abort(comm); } // the peers' rtmi_film_gather returns an error
+        } else if rtmi_film_gather(film, comm, 0, frame) != 0 {
+            err = Some(fail("rtmi_film_gather"));
+        } else if rank == 0 {
+            out = vec![0f32; 15 * (w as usize) * (h as usize)];
+            if rtmi_film_resolve(frame, out.as_mut_ptr(), 0) != 0 { err = Some(fail("rtmi_film_resolve")); }
+        }
+        if !film.is_null() { rtmi_film_destroy(film); }
         if !frame.is_null() { rtmi_film_destroy(frame); }
         if !comm.is_null() { rtmi_comm_destroy(comm); }
         match err { Some(e) => Err(e), None => Ok(out) }
