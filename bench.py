@@ -38,6 +38,24 @@ NODE_BYTES = 64
 RECORD_BYTES = 64
 RAY_BYTES = 24 + 20
 HBM_PEAK_GBS = 8000.0
+LINE_BYTES = 128
+# Scattered reads that miss L2 complete at one rate on this GPU whether 64 or 128 bytes of the line are used, from the
+# Infinity Cache and from HBM alike: 55.9 G lines/s (profiles/experiments/fetch_calib.hip, gather<64> / gather<128> on a
+# 512 MiB table; profiles/r03_pmc/fetch_calib.txt).  One fabric read request (TCC_EA0_RDREQ) is one such line.
+LINE_RATE_CEILING = 55.9e9
+
+
+def csrc_hash():
+    """sha256 over the library's sources: counter measurements (profiles/traffic.json) are only paired with timings of
+    the build they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracing_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse_args(argv=None):
@@ -189,6 +207,150 @@ def emit(line):
         os.write(_result_fd, data)
 
 
+def make_roofline(args, device, world_scene, film, camera, info, profile, steps, extend_ms, gpu_ms, launches, world, share):
+    """Roofline of the dominant kernel: the closest-hit launch of every bounce (BVH traversal + primitive tests;
+    extend_queue_kernel on the first two bounces, extend_kernel on the others: one piece of work scheduled two ways).
+
+    Times are this run's: HIP events around every launch on the library's stream, per bounce.  Bytes come from two
+    places.  (1) Counters: profiles/traffic.json holds, per launch of one frame of this workload, the fabric read
+    requests (TCC_EA0_RDREQ, one per 128-byte line: profiles/r03_pmc/fetch_calib.txt) and WRITE_SIZE from separate
+    rocprofv3 --pmc passes, stamped with the hash of the sources they were measured on; they are used only when that hash
+    is this build's.  `achieved` = (lines x 128 + bytes written) / time: what the memory side moves, whole lines counted,
+    and `frac` = that / the HBM peak.  (2) The algorithmic count of the same launches (64 bytes per node visit and
+    record test from device counters of an untimed render + ray and hit record), kept beside it as
+    algorithmic_rate_gbs: it prices bytes L2 serves against HBM and can exceed the peak, so it is not the fraction."""
+    from raytracing_amd import api
+    W, H = args.width, args.height
+    device.count_visits(True)
+    film_c = api.Film(device, film.xy)
+    st_c = api.render(world_scene, film_c, camera, args.spp, None, args.max_ray_depth, 0, args.seed,
+                      args.samples_per_pass)
+    nodes, records = device.visits()
+    device.count_visits(False)
+    film_c.close()
+    n_launch = max(launches // steps, 1)
+    # the bounces after the switch to tail_kernel (an eighth of a frame's rays on the headline workload) are traced
+    # by that kernel, which counts no visits; it is reported in its own block below
+    extend_rays = st_c["rays"] - st_c["tail_rays"]
+    alg_bytes = nodes * NODE_BYTES + records * RECORD_BYTES + extend_rays * RAY_BYTES
+    kernel_s = extend_ms / steps / 1e3
+    alg_rate = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+
+    # per bounce, from this run's events
+    per_bounce, tail = [], None
+    for (depth, kernel), acc in sorted(profile.items()):
+        row = {"depth": depth, "kernel": kernel, "rays": acc["rays"] // steps, "ms": acc["extend_ms"] / steps,
+               "shade_ms": acc["shade_ms"] / steps}
+        if kernel == "tail_kernel":
+            tail = row
+        else:
+            per_bounce.append(row)
+
+    # counters of the same launches, if they were taken on this build
+    tj, stale = None, None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    key = "%s_%dx%d_%dspp" % (args.scene, W, H, args.spp)
+    if os.path.exists(tfile) and world == 1 and share <= 1 and args.standin_extent is None:
+        try:
+            entry = json.load(open(tfile)).get(key)
+            if entry and entry.get("csrc_sha256") == csrc_hash():
+                tj = entry
+            elif entry:
+                stale = "profiles/traffic.json was measured on other sources (%s, this build %s)" % (
+                    entry.get("csrc_sha256"), csrc_hash())
+        except Exception as exc:  # noqa: BLE001
+            stale = "profiles/traffic.json unreadable: %s" % exc
+    traffic = achieved = None
+    line_rate = valu = None
+    if tj:
+        by_depth = {(r["depth"], r["kernel"]): r for r in tj["extend"]}
+        tot_bytes = tot_ms = deep_lines = deep_ms = 0.0
+        for row in per_bounce:
+            c = by_depth.get((row["depth"], row["kernel"]))
+            if not c or row["ms"] <= 0:
+                continue
+            row["lines"] = c["rdreq"]
+            row["hbm_bytes"] = c["rdreq"] * LINE_BYTES + c["write_kib"] * 1024.0
+            row["gbs"] = row["hbm_bytes"] / row["ms"] / 1e6
+            row["glines_per_s"] = c["rdreq"] / row["ms"] / 1e6
+            for k in ("l2_hit", "valu_busy", "lane_util", "ta_busy"):
+                if k in c:
+                    row[k] = c[k]
+            tot_bytes += row["hbm_bytes"]
+            tot_ms += row["ms"]
+            if row["depth"] >= 2:
+                deep_lines += c["rdreq"]
+                deep_ms += row["ms"]
+        if tot_ms > 0:
+            achieved = tot_bytes / tot_ms / 1e6
+            traffic = tot_bytes / n_launch
+        if deep_ms > 0:
+            line_rate = {"bounces": "2 and deeper (the memory-bound ones)", "glines_per_s": deep_lines / deep_ms / 1e6,
+                         "ceiling_glines_per_s": LINE_RATE_CEILING / 1e9,
+                         "frac": deep_lines / deep_ms / 1e6 / (LINE_RATE_CEILING / 1e9),
+                         "ceiling_from": "profiles/r03_pmc/fetch_calib.txt (scattered 64-B and 128-B reads: 55.9 G lines/s)"}
+        shallow = [r for r in per_bounce if r["depth"] < 2 and "valu_busy" in r]
+        if shallow:
+            valu = {"bounces": "0 and 1 (instruction-issue-bound)",
+                    "valu_issue_frac": sum(r["valu_busy"] * r["ms"] for r in shallow) / sum(r["ms"] for r in shallow),
+                    "lane_util": sum(r["lane_util"] * r["ms"] for r in shallow) / sum(r["ms"] for r in shallow)}
+        if tail and tj.get("tail") and tail["ms"] > 0:
+            c = tj["tail"]
+            tail["lines"] = c["rdreq"]
+            tail["hbm_bytes"] = c["rdreq"] * LINE_BYTES + c["write_kib"] * 1024.0
+            tail["gbs"] = tail["hbm_bytes"] / tail["ms"] / 1e6
+            tail["frac"] = tail["gbs"] / HBM_PEAK_GBS
+            tail["glines_per_s"] = c["rdreq"] / tail["ms"] / 1e6
+            for k in ("l2_hit", "valu_busy", "lane_util", "ta_busy"):
+                if k in c:
+                    tail[k] = c[k]
+    if tail:
+        tail["mrays_per_s"] = tail["rays"] / tail["ms"] / 1e3 if tail["ms"] > 0 else 0.0
+        tail["share_of_frame_ms"] = tail["ms"] / (gpu_ms / steps) if gpu_ms > 0 else None
+    scene_bytes = info["node_bytes"] + info["prim_bytes"]
+    residency = "L2 (4 MB per XCD)" if scene_bytes < 4e6 else \
+        "infinity cache (256 MB)" if scene_bytes < 128e6 else "hbm + infinity cache"
+    basis = "counters" if achieved is not None else "algorithmic"
+    if achieved is None:
+        achieved = alg_rate
+    return {
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "frac_basis": "memory-side bytes of these launches by the counters (fabric read requests x 128 B + bytes written) / "
+                      "their time, measured live" if basis == "counters" else
+                      "ALGORITHMIC bytes (no counter file for this build and workload%s): prices bytes L2 serves against "
+                      "HBM and can exceed 1" % ("; " + stale if stale else ""),
+        "kernel": "extend_kernel + extend_queue_kernel (the traversal launch of every bounce)",
+        "limited_by": "bounces 0-1: VALU issue at partial lane utilisation; deeper bounces: the rate at which the memory "
+                      "system completes scattered 128-byte line reads (line_rate below), of which a 64-byte node or record "
+                      "uses half",
+        "launches_per_step": n_launch,
+        "avg_launch_ms": extend_ms / max(launches, 1),
+        "kernel_ms_per_step": extend_ms / steps,
+        "other_kernels_ms_per_step": (gpu_ms - extend_ms) / steps,
+        "algorithmic_rate_gbs": alg_rate,
+        "algorithmic_bytes_per_step": alg_bytes,
+        "algorithmic_bytes_per_launch": alg_bytes / n_launch,
+        "rays_per_step": extend_rays,
+        "nodes_per_ray": nodes / max(extend_rays, 1),
+        "records_per_ray": records / max(extend_rays, 1),
+        "bytes_per_ray": alg_bytes / max(extend_rays, 1),
+        "line_rate": line_rate,
+        "valu": valu,
+        "per_bounce": per_bounce,
+        "tail": tail,
+        "scene_resident_in": residency,
+        "note": "scene: %.1f MB nodes + %.1f MB primitive records (64-B node / 64-B record gathers), resident in %s%s"
+                % (info["node_bytes"] / 1e6, info["prim_bytes"] / 1e6, residency,
+                   "" if residency == "hbm + infinity cache" else
+                   ": the kernel is not HBM-bound on this scene and the fraction of HBM peak says little"),
+    }
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -233,9 +395,11 @@ def main():
     info = world_scene.info()
     mesh = getattr(sg, "dragon_mesh", args.scene)
 
-    # RTMI_BENCH_SHARE=N: render only the share of tiles one rank of an N-rank job would own (scaling rehearsal on 1 GPU)
+    # RTMI_BENCH_SHARE=N [RTMI_BENCH_SHARE_RANK=r]: render only the share of tiles rank r (default 0) of an N-rank job
+    # would own (scaling rehearsal on 1 GPU)
     share = int(os.environ.get("RTMI_BENCH_SHARE", "0"))
-    my_tiles = api.tile_partition(tiler.tile_count(), share, 0) if share > 1 and world == 1 else \
+    share_rank = int(os.environ.get("RTMI_BENCH_SHARE_RANK", "0"))
+    my_tiles = api.tile_partition(tiler.tile_count(), share, share_rank) if share > 1 and world == 1 else \
         api.tile_partition(tiler.tile_count(), world, rank)
     block = tuple(int(v) for v in os.environ.get("RTMI_BENCH_BLOCK", "8x8").split("x"))
     film = api.Film.for_tiles(device, tiler, my_tiles, block if block[0] > 0 else None)
@@ -251,6 +415,7 @@ def main():
     comm = None
     gather_kind = "rtmi_film_gather (RCCL send/recv to rank 0)" if use_dist else "rtmi_film_gather (local scatter)"
     gatherer = frame_t = None
+    gather_fallback = None  # set when the library's gather could not be used: the JSON line is then marked invalid
 
     def use_torch_gather():
         nonlocal gatherer, frame_t
@@ -295,6 +460,7 @@ def main():
             sys.stderr.write("[bench rank %d] rtmi_film_gather unusable (%s); using torch.distributed for the gather\n"
                              % (rank, failure or "another rank failed"))
             gather_kind = "torch.distributed gather (rtmi_film_gather failed: %s)" % (failure or "on another rank")
+            gather_fallback = gather_kind
             gather = use_torch_gather()
         else:
             def gather():
@@ -324,8 +490,13 @@ def main():
     rays = paths = 0
     gpu_ms = bounce_ms = extend_ms = 0.0
     passes = launches = 0
+    profile = {}
     for _ in range(args.steps):
         st = step()
+        for b in device.last_render_profile():
+            acc = profile.setdefault((b["depth"], b["kernel"]), {"rays": 0, "extend_ms": 0.0, "shade_ms": 0.0, "launches": 0})
+            for k in acc:
+                acc[k] += b[k]
         rays += st["rays"]
         paths += st["paths"]
         gpu_ms += st["gpu_ms"]
@@ -353,65 +524,8 @@ def main():
         # with the visit counters on gives the node and record fetches
         roofline = None
         if not args.no_visits:
-            device.count_visits(True)
-            film_c = api.Film(device, film.xy)
-            st_c = api.render(world_scene, film_c, camera, args.spp, None, args.max_ray_depth, 0, args.seed,
-                              args.samples_per_pass)
-            nodes, records = device.visits()
-            device.count_visits(False)
-            film_c.close()
-            n_launch = max(launches // steps, 1)
-            # the last ~1 % of the rays of a frame are traced by tail_kernel, which neither counts visits nor is timed here
-            extend_rays = st_c["rays"] - st_c["tail_rays"]
-            alg_bytes = nodes * NODE_BYTES + records * RECORD_BYTES + extend_rays * RAY_BYTES
-            kernel_s = extend_ms / steps / 1e3
-            achieved = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tfile):
-                try:
-                    tj = json.load(open(tfile))
-                    key = "%s_%dx%d_%dspp" % (args.scene, W, H, args.spp)
-                    if key in tj and world == 1 and share <= 1 and args.standin_extent is None:
-                        traffic = tj[key]["hbm_bytes_per_launch"]
-                except Exception:
-                    traffic = None
-            scene_bytes = info["node_bytes"] + info["prim_bytes"]
-            residency = "L2 (4 MB per XCD)" if scene_bytes < 4e6 else \
-                "infinity cache (256 MB)" if scene_bytes < 128e6 else "hbm + infinity cache"
-            roofline = {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": "extend_kernel + extend_queue_kernel (the traversal launch of every bounce)",
-                "limited_by": "bounces 0-1: VALU issue at partial lane utilisation; deeper bounces: the rate at which "
-                              "the memory system returns scattered 128-byte lines (TA busy 0.9-0.99, SQ / TCP / TCC "
-                              "counters in profiles/); priced against HBM peak because the algorithmic work is bytes "
-                              "gathered, not flops",
-                "launches_per_step": n_launch,
-                "avg_launch_ms": extend_ms / max(launches, 1),
-                # the counters' side of the same launch: HBM bytes actually moved per second (the top of the tree is
-                # served by L2, so the algorithmic rate above can exceed what HBM delivers, and even its peak)
-                "traffic_rate_gbs": (traffic / (extend_ms / max(launches, 1) * 1e-3) / 1e9) if traffic else None,
-                "traffic_frac": (traffic / (extend_ms / max(launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "kernel_ms_per_step": extend_ms / steps,
-                "other_kernels_ms_per_step": (gpu_ms - extend_ms) / steps,
-                "algorithmic_bytes_per_step": alg_bytes,
-                "algorithmic_bytes_per_launch": alg_bytes / n_launch,
-                "rays_per_step": extend_rays,
-                "tail_kernel_rays_per_step": st_c["tail_rays"],
-                "nodes_per_ray": nodes / max(extend_rays, 1),
-                "records_per_ray": records / max(extend_rays, 1),
-                "bytes_per_ray": alg_bytes / max(extend_rays, 1),
-                "scene_resident_in": residency,
-                "note": "scene: %.1f MB nodes + %.1f MB primitive records (64-B node / 64-B record gathers), resident in %s%s"
-                        % (info["node_bytes"] / 1e6, info["prim_bytes"] / 1e6, residency,
-                           "" if residency == "hbm + infinity cache" else
-                           ": the kernel is not HBM-bound on this scene and the fraction of HBM peak says little"),
-            }
+            roofline = make_roofline(args, device, world_scene, film, camera, info, profile, steps, extend_ms, gpu_ms,
+                                     launches, world, share)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, camera, tiler)
@@ -446,6 +560,10 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if gather_fallback:
+            # the exchange step measured is not the library's: not a number for this build's multi-GPU path
+            out["valid"] = False
+            out["invalid_reason"] = gather_fallback
         emit(json.dumps(out))
     film.close()
     if frame is not None:

@@ -136,6 +136,19 @@ typedef struct rtmi_render_stats {
     uint64_t tail_rays; /* of `rays`: traced by the run-to-completion kernel that finishes the last few paths of a pass */
 } rtmi_render_stats;
 
+/* Where the device time of the last rtmi_render on a device went, bounce by bounce (rtmi_device_last_render_profile).
+ * The reference times one scope, the whole tile phase (rt-cli/src/renderer.rs:65); it has no per-bounce view. */
+enum { RTMI_KERNEL_EXTEND = 0, RTMI_KERNEL_EXTEND_QUEUE = 1, RTMI_KERNEL_TAIL = 2 };
+typedef struct rtmi_bounce_profile {
+    uint32_t depth;    /* bounce; for RTMI_KERNEL_TAIL the first bounce the run-to-completion kernel took over */
+    uint32_t kernel;   /* RTMI_KERNEL_*: which closest-hit kernel traced the bounce */
+    uint64_t rays;     /* rays traced at this bounce (RTMI_KERNEL_TAIL: at this and every deeper bounce), all passes */
+    float extend_ms;   /* device time inside the closest-hit launches (RTMI_KERNEL_TAIL: inside the tail launches) */
+    float shade_ms;    /* device time inside the shading launches of the bounce (0 for the tail, which shades inside) */
+    uint32_t launches; /* closest-hit launches added up in this entry (one per pass that reached the bounce) */
+    uint32_t reserved;
+} rtmi_bounce_profile;
+
 typedef struct rtmi_scene_info {
     uint64_t n_prims;
     uint64_t n_nodes;
@@ -169,6 +182,10 @@ void *rtmi_device_stream(rtmi_device *dev);
  * render adds its BVH node fetches to out[0] and its primitive tests to out[1].  Enabling resets both. */
 int rtmi_device_count_visits(rtmi_device *dev, int enable);
 int rtmi_device_get_visits(rtmi_device *dev, uint64_t out[2]);
+/* Per-bounce device times and ray counts of the last rtmi_render that finished on this device (HIP events around every
+ * launch on the library's stream): up to `capacity` entries into out, ordered by bounce; *n_out = entries available.
+ * No counterpart in the reference (its only timer is the "run tile renderer" scope, rt-cli/src/renderer.rs:65). */
+int rtmi_device_last_render_profile(rtmi_device *dev, rtmi_bounce_profile *out, uint32_t capacity, uint32_t *n_out);
 
 /* EmbreeScene::new (embree.rs:29-51): material 0 is the black "Sky" diffuse. */
 int rtmi_scene_create(rtmi_device *dev, rtmi_scene **out);

@@ -53,6 +53,11 @@ class RenderStats(C.Structure):
                 ("tail_rays", C.c_uint64)]
 
 
+class BounceProfile(C.Structure):
+    _fields_ = [("depth", C.c_uint32), ("kernel", C.c_uint32), ("rays", C.c_uint64), ("extend_ms", C.c_float),
+                ("shade_ms", C.c_float), ("launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class SceneInfo(C.Structure):
     _fields_ = [("n_prims", C.c_uint64), ("n_nodes", C.c_uint64), ("node_bytes", C.c_uint64),
                 ("prim_bytes", C.c_uint64), ("n_geoms", C.c_uint32), ("n_materials", C.c_uint32),
@@ -77,6 +82,7 @@ SIGNATURES = {
     "rtmi_device_stream": (_vp, [_vp]),
     "rtmi_device_count_visits": (C.c_int, [_vp, C.c_int]),
     "rtmi_device_get_visits": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "rtmi_device_last_render_profile": (C.c_int, [_vp, _vp, _u32, _u32p]),
     "rtmi_scene_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "rtmi_scene_destroy": (None, [_vp]),
     "rtmi_scene_insert_material": (C.c_int, [_vp, C.POINTER(Material), _u32p]),

@@ -59,6 +59,19 @@ class Device:
     def count_visits(self, enable=True):
         check(self._l.rtmi_device_count_visits(self._h, 1 if enable else 0))
 
+    KERNELS = ("extend_kernel", "extend_queue_kernel", "tail_kernel")
+
+    def last_render_profile(self):
+        """rtmi_device_last_render_profile: per bounce, the kernel that traced it, its rays and the device time inside
+        its closest-hit and shading launches, for the last render on this device."""
+        n = C.c_uint32()
+        check(self._l.rtmi_device_last_render_profile(self._h, None, 0, C.byref(n)))
+        buf = (_lib.BounceProfile * max(n.value, 1))()
+        check(self._l.rtmi_device_last_render_profile(self._h, buf, n.value, C.byref(n)))
+        return [{"depth": int(b.depth), "kernel": self.KERNELS[b.kernel], "rays": int(b.rays),
+                 "extend_ms": float(b.extend_ms), "shade_ms": float(b.shade_ms), "launches": int(b.launches)}
+                for b in buf[:n.value]]
+
     def visits(self):
         out = (C.c_uint64 * 2)()
         check(self._l.rtmi_device_get_visits(self._h, out))

@@ -205,6 +205,14 @@ int rtmi_device_get_visits(rtmi_device *dev, uint64_t out[2]) {
     return RTMI_OK;
 }
 
+int rtmi_device_last_render_profile(rtmi_device *dev, rtmi_bounce_profile *out, uint32_t capacity, uint32_t *n_out) {
+    if (!dev || !n_out || (capacity && !out)) return fail(RTMI_ERR_ARG, "rtmi_device_last_render_profile: NULL argument");
+    std::lock_guard<std::mutex> g(dev->lock);
+    *n_out = (uint32_t)dev->profile.size();
+    for (uint32_t i = 0; i < capacity && i < dev->profile.size(); ++i) out[i] = dev->profile[i];
+    return RTMI_OK;
+}
+
 void *rtmi_device_stream(rtmi_device *dev) { return dev ? (void *)dev->stream : nullptr; }
 
 int rtmi_scene_create(rtmi_device *dev, rtmi_scene **out) {
@@ -857,6 +865,14 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     }
     Stopwatch watch;
     float total_ms = 0.0f, bounce_ms = 0.0f, extend_ms = 0.0f;
+    // per-bounce view of the same launches (rtmi_device_last_render_profile); sized once, the stopwatch keeps pointers
+    struct BounceTimes {
+        float extend_ms[2] = {0.0f, 0.0f}; // by kernel: voting, queued
+        float shade_ms = 0.0f, tail_ms = 0.0f;
+        uint32_t launches[2] = {0, 0}, tail_launches = 0;
+        uint64_t rays = 0, tail_rays = 0;
+    };
+    std::vector<BounceTimes> prof((size_t)params->max_depth + 1);
     const int t_total = watch.start(stream, &total_ms);
     if (t_total < 0) return fail(RTMI_ERR_DEVICE, "hipEventCreate failed");
     int rc = RTMI_OK;
@@ -936,8 +952,11 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
                 a.refill_below = tail_refill;
                 a.tail_shade = tail_shade;
                 a.queue_low = queue_low;
+                const int t_tail = watch.start(stream, &prof[depth].tail_ms);
                 if (rtk::launch_tail(a, depth, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(scene->grid_blocks_tail, want)), stream))
                     rc = fail(RTMI_ERR_DEVICE, "tail kernel launch failed");
+                watch.stop(t_tail, stream);
+                ++prof[depth].tail_launches;
                 tail_from = depth;
                 launched = params->max_depth;
                 break;
@@ -954,9 +973,16 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
             // timed on its own: the traversal launch is what the roofline of the dominant kernel needs
             const int t_extend = watch.start(stream, &extend_ms);
             a.refill_below = a.queue_low > 0 ? queue_refill : vote_refill;
+            const int which = a.queue_low > 0 && a.visit_counters == nullptr ? 1 : 0;
+            const int t_extend_d = watch.start(stream, &prof[depth].extend_ms[which]);
             int lrc = rtk::launch_extend(a, depth, grid, stream);
             watch.stop(t_extend, stream);
-            if (lrc || rtk::launch_shade(a, depth, longest, stream)) {
+            watch.stop(t_extend_d, stream);
+            ++prof[depth].launches[which];
+            const int t_shade = watch.start(stream, &prof[depth].shade_ms);
+            if (!lrc) lrc = rtk::launch_shade(a, depth, longest, stream);
+            watch.stop(t_shade, stream);
+            if (lrc) {
                 rc = fail(RTMI_ERR_DEVICE, "extend or shade kernel launch failed");
                 break;
             }
@@ -988,6 +1014,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         // exact ray count and deepest bounce of the pass from the counters of every bounce that ran (read in chunks
         // of 256 bounces up to the first empty one: live counts never grow from one bounce to the next)
         rays += camera_rays;
+        prof[0].rays += camera_rays;
         bool ended = false;
         for (uint32_t d0 = 1; d0 < launched && !ended; d0 += 256) {
             const uint32_t d1 = std::min(launched, d0 + 256);
@@ -1004,7 +1031,12 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
                     break;
                 }
                 rays += n_d;
-                if (tail_from != 0 && d >= tail_from) tail_rays_traced += n_d;
+                if (tail_from != 0 && d >= tail_from) {
+                    tail_rays_traced += n_d;
+                    prof[tail_from].tail_rays += n_d;
+                } else {
+                    prof[d].rays += n_d;
+                }
                 if (d > deepest) deepest = d;
             }
         }
@@ -1016,6 +1048,21 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     hipError_t e = hipStreamSynchronize(stream);
     if (rc == RTMI_OK && e != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
     if (e == hipSuccess) watch.collect();
+    if (rc == RTMI_OK && e == hipSuccess) {
+        dev->profile.clear();
+        for (uint32_t d = 0; d < prof.size(); ++d) {
+            const BounceTimes &b = prof[d];
+            for (uint32_t k = 0; k < 2; ++k)
+                if (b.launches[k]) {
+                    // rays and shading time of a bounce traced by both kernels (in different passes) go to the first entry
+                    const bool first = k == 0 || b.launches[0] == 0;
+                    dev->profile.push_back(rtmi_bounce_profile{d, k, first ? b.rays : 0, b.extend_ms[k], first ? b.shade_ms : 0.0f,
+                                                               b.launches[k], 0});
+                }
+            if (b.tail_launches)
+                dev->profile.push_back(rtmi_bounce_profile{d, RTMI_KERNEL_TAIL, b.tail_rays, b.tail_ms, 0.0f, b.tail_launches, 0});
+        }
+    }
     if (rc == RTMI_OK && stats) {
         stats->rays = rays;
         stats->tail_rays = tail_rays_traced;

@@ -73,6 +73,7 @@ struct rtmi_device {
     uint32_t *h_counts = nullptr; // COUNT_RING slots of SEGMENTS * COUNTER_STRIDE words, pinned
     hipEvent_t ev_shaded[COUNT_RING] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_copied[COUNT_RING] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<rtmi_bounce_profile> profile; // of the last render (under `lock`)
     std::atomic<int> refs{1}; // the handle itself + one per scene and film created on it
 };
 

@@ -789,3 +789,75 @@ extern "C" void hs_queue_sim(void *p, const Ray *rays, size_t n, int refill_belo
         }
     }
 }
+
+// Every item (inner node: its index; primitive record: RT_LEAF | slot) a ray's closest-hit traversal fetches, in visit
+// order, for layout studies: ray i's items are items[offsets[i] .. offsets[i + 1]).  Returns the number of items the
+// rays fetch in total; items beyond `cap` are counted but not stored.
+extern "C" size_t hs_trace(void *p, const Ray *rays, size_t n, uint32_t *items, size_t cap, uint64_t *offsets) {
+    Scene *s = (Scene *)p;
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        offsets[i] = total;
+        V3 o = mk(rays[i].org[0], rays[i].org[1], rays[i].org[2]);
+        V3 d = mk(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
+        VecStack st;
+        Trav tr;
+        trav_begin(s->view, o, d, rays[i].tfar, tr);
+        while (tr.cur != RT_EMPTY) {
+            if (!(tr.cur & RT_LEAF)) {
+                if (total < cap) items[total] = tr.cur;
+                ++total;
+                trav_node_step(s->view, rays[i].tnear, tr, st);
+            } else {
+                if (total < cap) items[total] = RT_LEAF | (tr.cur & 0x0FFFFFFFu);
+                ++total;
+                trav_leaf_step(s->view, o, d, rays[i].tnear, tr, st);
+            }
+        }
+    }
+    offsets[n] = total;
+    return total;
+}
+
+// The flattened tree: n_nodes x 16 words.
+extern "C" size_t hs_nodes(void *p, uint32_t *out, size_t max_nodes) {
+    Scene *s = (Scene *)p;
+    const size_t n = s->bvh.n_nodes < max_nodes ? s->bvh.n_nodes : max_nodes;
+    if (out) memcpy(out, s->bvh.nodes.data(), n * 64);
+    return s->bvh.n_nodes;
+}
+
+// The rays real paths trace at bounce `depth_wanted` (the path tracer's own bounce rays, not synthetic ones): runs
+// every sample of the listed pixels and stores the ray entering that bounce.  Returns the number of rays stored.
+extern "C" size_t hs_path_rays(void *p, const CameraView *cam, const Params *prm, const uint32_t *xy, size_t npix,
+                               uint32_t depth_wanted, Ray *out, size_t cap) {
+    Scene *s = (Scene *)p;
+    uint32_t strata = (uint32_t)floorf(sqrtf((float)prm->spp));
+    if (strata == 0) strata = 1;
+    size_t n = 0;
+    for (size_t i = 0; i < npix && n < cap; ++i)
+        for (uint32_t sample = prm->sample_begin; sample < prm->sample_end && n < cap; ++sample) {
+            V3 org, dir, beta = mk(1.0f, 1.0f, 1.0f);
+            camera_ray(*cam, strata, prm->flags, prm->seed, xy[2 * i], xy[2 * i + 1], sample, org, dir);
+            for (uint32_t depth = 0; depth < prm->max_depth; ++depth) {
+                if (depth == depth_wanted) {
+                    Ray &r = out[n++];
+                    r.org[0] = org.x, r.org[1] = org.y, r.org[2] = org.z;
+                    r.dir[0] = dir.x, r.dir[1] = dir.y, r.dir[2] = dir.z;
+                    r.tnear = RT_TNEAR;
+                    r.tfar = INFINITY;
+                    break;
+                }
+                VecStack st;
+                Closest best;
+                closest_hit(s->view, org, dir, RT_TNEAR, INFINITY, st, best, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                HitInfo h;
+                finish_hit(s->view, org, dir, best, h);
+                VertexOut vo;
+                if (!shade_vertex(s->view, h, prm->integrator, prm->seed, xy[2 * i], xy[2 * i + 1], sample, depth, org,
+                                  dir, beta, vo))
+                    break;
+            }
+        }
+    return n;
+}

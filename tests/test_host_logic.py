@@ -51,7 +51,7 @@ def test_structure_layouts_match_the_header():
     assert _lib.RAY_DTYPE.itemsize == 32 and _lib.HIT_DTYPE.itemsize == 48
     assert C.sizeof(_lib.Camera) == 52 and C.sizeof(_lib.TransformPOD) == 40
     assert C.sizeof(_lib.RenderParams) == 40 and C.sizeof(_lib.RenderStats) == 48
-    assert C.sizeof(_lib.SceneInfo) == 56
+    assert C.sizeof(_lib.SceneInfo) == 56 and C.sizeof(_lib.BounceProfile) == 32
 
 
 def test_no_gpu_fails_loudly():
