@@ -9,8 +9,11 @@ already fetched that line.  Layouts:
 Usage: python profiles/experiments/layout_sim.py [levels] [pixel stride]
 """
 import ctypes as C
+import os
 import sys
 import time
+
+os.environ.pop("RTMI_LAYOUT", None)  # the tree in its breadth-first placement: item index = node index
 
 sys.path.insert(0, ".")
 import numpy as np  # noqa: E402
@@ -26,8 +29,8 @@ EMPTY, LEAF = 0xFFFFFFFF, 0x80000000
 L = HS.lib()
 L.hs_trace.restype = C.c_size_t
 L.hs_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
-L.hs_nodes.restype = C.c_size_t
-L.hs_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+L.hs_items.restype = C.c_size_t
+L.hs_items.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 L.hs_path_rays.restype = C.c_size_t
 L.hs_path_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]
 
@@ -36,13 +39,17 @@ sh = HS.HostSimScene()
 scenes.DragonScene.insert_into(sh, levels=levels)
 sh.commit()
 print("scene", sh.info, "%.0f s" % (time.time() - t0), flush=True)
-n_nodes = L.hs_nodes(sh._h, None, 0)
-nodes = np.zeros((n_nodes, 16), dtype=np.uint32)
-L.hs_nodes(sh._h, nodes.ctypes.data, n_nodes)
-refs = nodes[:, 12:16]
+n_nodes = sh.info["n_nodes"]
+n_items = L.hs_items(sh._h, None, 0)
+nodes = np.zeros((n_items, 16), dtype=np.uint32)
+L.hs_items(sh._h, nodes.ctypes.data, n_items)
+nodes = nodes[:n_nodes]
+rec_base = (n_nodes + 1) // 2 * 2
+refs = nodes[:, 12:16].copy()
 is_leaf = (refs & LEAF) != 0
 valid = refs != EMPTY
 is_leaf &= valid
+refs[is_leaf] -= rec_base  # leaf references as record slots
 slots = (refs & 0x0FFFFFFF)
 n_rec = int(slots[is_leaf].max()) + 1
 print("nodes %d records %d" % (n_nodes, n_rec))
@@ -135,6 +142,8 @@ for depth in (1, 2, 3, 5, 8):
     total = L.hs_trace(sh._h, rays.ctypes.data, n, None, 0, offsets.ctypes.data)
     items = np.zeros(total, dtype=np.uint32)
     L.hs_trace(sh._h, rays.ctypes.data, n, items.ctypes.data, total, offsets.ctypes.data)
+    leaf = (items & LEAF) != 0
+    items[leaf] -= rec_base
     traces[depth] = (items, offsets.astype(np.int64))
     origins[depth] = rays["org"].copy()
     print("depth %d: %d rays, %.1f items per ray (%.0f s)" % (depth, n, total / max(n, 1), time.time() - t0), flush=True)

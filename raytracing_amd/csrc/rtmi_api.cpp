@@ -353,26 +353,25 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
     const auto t0 = std::chrono::steady_clock::now();
     const size_t n = scene->prims.size();
     rtb::WideBvh bvh;
-    std::vector<rtd::F4> prims;
+    size_t n_records = 0;
     std::function<bool(double)> cb;
     if (progress) cb = [progress, user](double a) { return progress(a, user) != 0; };
-    if (!rts::build_scene(scene->prims, bvh, prims, scene->lo, scene->hi, cb))
+    if (!rts::build_scene(scene->prims, bvh, &n_records, scene->lo, scene->hi, cb))
         return fail(RTMI_ERR_CANCELLED, "commit cancelled by the progress callback");
-    if (bvh.n_nodes >= rtd::RT_MAX_ITEMS || prims.size() / rtd::RT_PRIM_F4 >= rtd::RT_MAX_ITEMS)
-        return fail(RTMI_ERR_LIMIT, "scene too large: more than 2^26 BVH nodes or primitive records");
+    if (bvh.n_items >= rtd::RT_MAX_ITEMS)
+        return fail(RTMI_ERR_LIMIT, "scene too large: more than 2^26 BVH nodes and primitive records");
     if (bvh.stack_need > rtk::MAX_STACK)
         return fail(RTMI_ERR_LIMIT, "BVH needs a deeper traversal stack than the kernels provide");
     free_scene_device(scene);
-    const size_t node_bytes = bvh.nodes.size() * sizeof(rtd::F4);
-    const size_t prim_bytes = prims.size() * sizeof(rtd::F4);
-    if (node_bytes) {
-        HIP_TRY(hipMalloc((void **)&scene->d_nodes, node_bytes));
-        HIP_TRY(hipMemcpy(scene->d_nodes, bvh.nodes.data(), node_bytes, hipMemcpyHostToDevice));
+    // nodes and primitive records live in one array of 64-byte items (see bvh.h)
+    const size_t item_bytes = bvh.items.size() * sizeof(rtd::F4);
+    const size_t node_bytes = (size_t)bvh.n_nodes * 64;
+    const size_t prim_bytes = item_bytes - node_bytes; // records and the padding of the layout
+    if (item_bytes) {
+        HIP_TRY(hipMalloc((void **)&scene->d_nodes, item_bytes));
+        HIP_TRY(hipMemcpy(scene->d_nodes, bvh.items.data(), item_bytes, hipMemcpyHostToDevice));
     }
-    if (prim_bytes) {
-        HIP_TRY(hipMalloc((void **)&scene->d_prims, prim_bytes));
-        HIP_TRY(hipMemcpy(scene->d_prims, prims.data(), prim_bytes, hipMemcpyHostToDevice));
-    }
+    scene->d_prims = nullptr; // records are addressed through the same base as nodes
     const size_t gm_bytes = std::max<size_t>(1, scene->geom_material.size()) * sizeof(uint32_t);
     HIP_TRY(hipMalloc((void **)&scene->d_geom_material, gm_bytes));
     if (!scene->geom_material.empty())
@@ -393,7 +392,7 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
         HIP_TRY(hipMalloc((void **)&scene->d_spill, scene->spill_bytes));
     }
     scene->view.nodes = scene->d_nodes;
-    scene->view.prims = scene->d_prims;
+    scene->view.prims = scene->d_nodes;
     scene->view.geom_material = scene->d_geom_material;
     scene->view.materials = scene->d_materials;
     scene->view.n_nodes = bvh.n_nodes;

@@ -2,6 +2,7 @@
 #include "scene_build.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -181,8 +182,8 @@ void pair_triangles(const std::vector<HostPrim> &prims, const std::vector<rtb::B
 
 } // namespace
 
-bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, std::vector<rtd::F4> &records, float lo[3],
-                 float hi[3], const std::function<bool(double)> &progress) {
+bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, size_t *n_records, float lo[3], float hi[3],
+                 const std::function<bool(double)> &progress) {
     const size_t n = prims.size();
     std::vector<rtb::Box> boxes(n);
     for (int k = 0; k < 3; ++k) {
@@ -226,8 +227,11 @@ bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, std::vec
         if (prims[i].geom >= geom_first.size()) geom_first.resize(prims[i].geom + 1, NONE);
         if (geom_first[prims[i].geom] == NONE) geom_first[prims[i].geom] = (uint32_t)i;
     }
-    if (!rtb::build(rec_boxes, bvh, progress)) return false;
-    records.assign(nr * rtd::RT_PRIM_F4, rtd::F4{0.0f, 0.0f, 0.0f, 0.0f});
+    rtb::Layout layout = rtb::Layout::BFS;
+    if (const char *v = getenv("RTMI_LAYOUT"))
+        if (strcmp(v, "pairs") == 0) layout = rtb::Layout::PAIRS;
+    if (!rtb::build(rec_boxes, bvh, progress, 0, layout)) return false;
+    if (n_records) *n_records = nr;
     for (size_t slot = 0; slot < nr; ++slot) {
         const uint32_t i = rec_first[bvh.prim_order[slot]], j = mate[i];
         const HostPrim &p = prims[i];
@@ -271,7 +275,7 @@ bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, std::vec
             }
         }
         memcpy(&w[12], ids, 16);
-        memcpy(&records[slot * rtd::RT_PRIM_F4], w, 64);
+        memcpy(&bvh.items[(size_t)bvh.record_item[slot] * rtd::RT_PRIM_F4], w, 64);
     }
     return true;
 }

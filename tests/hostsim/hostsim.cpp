@@ -38,7 +38,6 @@ struct Scene {
     std::vector<rts::HostPrim> prims;
     std::vector<uint32_t> geom_material;
     rtb::WideBvh bvh;
-    std::vector<F4> records;
     float lo[3], hi[3];
     SceneView view{};
     int stack_high = 0;
@@ -146,9 +145,9 @@ int hs_load_obj(void *p, const char *path, const float tr[3], const float sc[3],
 // out: n_prims, n_nodes, stack_need, depth
 int hs_commit(void *p, uint32_t out[4]) {
     Scene *s = (Scene *)p;
-    if (!rts::build_scene(s->prims, s->bvh, s->records, s->lo, s->hi, nullptr)) return -1;
-    s->view.nodes = s->bvh.nodes.data();
-    s->view.prims = s->records.data();
+    if (!rts::build_scene(s->prims, s->bvh, nullptr, s->lo, s->hi, nullptr)) return -1;
+    s->view.nodes = s->bvh.items.data();
+    s->view.prims = s->bvh.items.data();
     s->view.geom_material = s->geom_material.data();
     s->view.materials = s->materials.data();
     s->view.n_nodes = s->bvh.n_nodes;
@@ -819,12 +818,14 @@ extern "C" size_t hs_trace(void *p, const Ray *rays, size_t n, uint32_t *items, 
     return total;
 }
 
-// The flattened tree: n_nodes x 16 words.
-extern "C" size_t hs_nodes(void *p, uint32_t *out, size_t max_nodes) {
+// The item array of the tree (nodes and primitive records, 16 words each); returns the number of items.  In the default (breadth-first)
+// placement items [0, n_nodes) are the nodes breadth-first and the records follow
+// from the next even index on.
+extern "C" size_t hs_items(void *p, uint32_t *out, size_t max_items) {
     Scene *s = (Scene *)p;
-    const size_t n = s->bvh.n_nodes < max_nodes ? s->bvh.n_nodes : max_nodes;
-    if (out) memcpy(out, s->bvh.nodes.data(), n * 64);
-    return s->bvh.n_nodes;
+    const size_t n = s->bvh.n_items < max_items ? s->bvh.n_items : max_items;
+    if (out) memcpy(out, s->bvh.items.data(), n * 64);
+    return s->bvh.n_items;
 }
 
 // The rays real paths trace at bounce `depth_wanted` (the path tracer's own bounce rays, not synthetic ones): runs
