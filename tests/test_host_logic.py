@@ -199,7 +199,6 @@ def test_device_code_on_host_matches_oracle(oracle, hostsim, scene_classes, name
     assert sh.stack_high() <= sh.info["stack_need"] <= 128
 
 
-@pytest.mark.parametrize("aperture", [0.0, 0.1])
 @pytest.mark.parametrize("name,kw", [("cornell-box", {}), ("bunny", {}), ("dragon", {"levels": 1})])
 def test_paired_item_layout_changes_no_result(oracle, hostsim, scene_classes, monkeypatch, name, kw):
     """RTMI_LAYOUT=pairs places every node next to its largest child in the item array (csrc/bvh.h).  Placement is not
@@ -221,6 +220,7 @@ def test_paired_item_layout_changes_no_result(oracle, hostsim, scene_classes, mo
     assert rays_o == rays_h and same_bits(acc_o, acc_h).all()
 
 
+@pytest.mark.parametrize("aperture", [0.0, 0.1])
 def test_optics_lab_on_host_matches_oracle(oracle, hostsim, aperture):
     """Thin dielectric, smooth dielectric, ior == 1 and the thin-lens, rotated camera: the device code built for the
     host against the oracle, bit for bit; and the scene does reach the branches it is meant to reach."""
