@@ -713,7 +713,9 @@ __device__ __forceinline__ bool channel_precise(float count, float sum, float sq
 // next entry of the queue of bounce depth0.  The launch lasts about as long as the deepest path while the other lanes
 // work through the short ones.  After every shading phase the wave adds its surviving lanes to the counters of the
 // bounces they enter, so the counters read like those of the wavefront kernels.
-__global__ __launch_bounds__(BLOCK) void tail_kernel(RenderArgs a, uint32_t depth0) {
+// Five waves per SIMD (96 registers, a dozen of them spilled around the shading step) measured faster than four without
+// spills and than six with thirty.
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void tail_kernel(RenderArgs a, uint32_t depth0) {
     __shared__ ExtendQueueLds lds;
     QueueStack st = make_stack_of<QUEUE_STACK>(lds.stack, a.spill);
     const size_t P = a.n_paths;

@@ -877,7 +877,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     int rc = RTMI_OK;
     uint32_t sample = params->sample_begin;
     uint64_t rays = 0, paths = 0, tail_rays_traced = 0;
-    uint64_t tail_rays = 1u << 24;
+    uint64_t tail_rays = 1u << 25;
     if (const char *v = getenv("RTMI_TAIL_RAYS")) tail_rays = (uint64_t)atoll(v);
     uint32_t deepest = 0, launches = 0;
     uint32_t n_done = 0; // pixels already precise enough for this call (use_done only)
