@@ -33,7 +33,11 @@ def short(kernel):
 
 # counter -> kernel -> [(dispatch id, value)]
 data = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
+files = glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv"))
+passes = [os.path.relpath(f, src).split(os.sep)[0] for f in files]
+if len(set(passes)) != len(passes):
+    raise SystemExit("more than one counter file per pass under %s (a previous run's files?): %s" % (src, sorted(files)))
+for f in files:
     for r in csv.DictReader(open(f)):
         if "rtk::" not in r["Kernel_Name"]:
             continue
