@@ -281,9 +281,15 @@ def make_roofline(args, device, world_scene, film, camera, info, profile, steps,
             if row["depth"] >= 2:
                 deep_lines += c["rdreq"]
                 deep_ms += row["ms"]
+        n_counted = len([r for r in per_bounce if "hbm_bytes" in r])
+        if tail and tj.get("tail") and tail["ms"] > 0:
+            # tail_kernel is the same traversal for the bounces after the switch (with the shading step inside it)
+            tot_bytes += tj["tail"]["rdreq"] * LINE_BYTES + tj["tail"]["write_kib"] * 1024.0
+            tot_ms += tail["ms"]
+            n_counted += 1
         if tot_ms > 0:
             achieved = tot_bytes / tot_ms / 1e6
-            traffic = tot_bytes / n_launch
+            traffic = tot_bytes / max(n_counted, 1)
         if deep_ms > 0:
             line_rate = {"bounces": "2 and deeper (the memory-bound ones)", "glines_per_s": deep_lines / deep_ms / 1e6,
                          "ceiling_glines_per_s": LINE_RATE_CEILING / 1e9,
@@ -324,14 +330,20 @@ def make_roofline(args, device, world_scene, film, camera, info, profile, steps,
                       "their time, measured live" if basis == "counters" else
                       "ALGORITHMIC bytes (no counter file for this build and workload%s): prices bytes L2 serves against "
                       "HBM and can exceed 1" % ("; " + stale if stale else ""),
-        "kernel": "extend_kernel + extend_queue_kernel (the traversal launch of every bounce)",
+        "kernel": "the traversal launches of a frame: extend_queue_kernel (bounces 0-1), extend_kernel (the bounces up to "
+                  "the switch), tail_kernel (all later bounces in one launch)" if basis == "counters" else
+                  "extend_kernel + extend_queue_kernel (the traversal launch of every wavefront bounce)",
         "limited_by": "bounces 0-1: VALU issue at partial lane utilisation; deeper bounces: the rate at which the memory "
                       "system completes scattered 128-byte line reads (line_rate below), of which a 64-byte node or record "
                       "uses half",
-        "launches_per_step": n_launch,
-        "avg_launch_ms": extend_ms / max(launches, 1),
-        "kernel_ms_per_step": extend_ms / steps,
-        "other_kernels_ms_per_step": (gpu_ms - extend_ms) / steps,
+        "launches_per_step": n_launch + (1 if tail and basis == "counters" else 0),
+        "avg_launch_ms": (extend_ms / steps + (tail["ms"] if tail and basis == "counters" else 0.0)) /
+                         (n_launch + (1 if tail and basis == "counters" else 0)),
+        "kernel_ms_per_step": extend_ms / steps + (tail["ms"] if tail and basis == "counters" else 0.0),
+        "other_kernels_ms_per_step": (gpu_ms - extend_ms) / steps - (tail["ms"] if tail and basis == "counters" else 0.0),
+        "wavefront_launches_per_step": n_launch,
+        "wavefront_ms_per_step": extend_ms / steps,
+        # the algorithmic figures cover the wavefront launches only (tail_kernel counts no visits)
         "algorithmic_rate_gbs": alg_rate,
         "algorithmic_bytes_per_step": alg_bytes,
         "algorithmic_bytes_per_launch": alg_bytes / n_launch,
