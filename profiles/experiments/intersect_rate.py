@@ -23,6 +23,8 @@ cam = types.Camera.from_dimensions(W, H)
 so = O.OracleScene()
 cam_rays = so.camera_rays(cam, O.make_params(spp=100), full_frame_xy(W, H), 3)
 cam_rays["tnear"], cam_rays["tfar"] = 1e-5, np.inf
+cam8 = np.concatenate([cam_rays] + [so.camera_rays(cam, O.make_params(spp=100), full_frame_xy(W, H), k) for k in range(4, 11)])
+cam8["tnear"], cam8["tfar"] = 1e-5, np.inf
 first = world.intersect(cam_rays)
 hit = first["geom_id"] == 0  # the mesh
 pts = first["pos"][hit]
@@ -37,7 +39,7 @@ inc["org"], inc["dir"] = a[ok], d[ok] / ln[ok][:, None]
 inc["tnear"], inc["tfar"] = 1e-5, np.inf
 stream = hip_rt.Stream()
 sp = C.c_void_p(stream.handle)
-for name, rays, entry in (("camera rays", cam_rays, world.intersect_device), ("surface-to-surface rays", inc, world.intersect_device),
+for name, rays, entry in (("camera rays", cam_rays, world.intersect_device), ("camera rays, 8 samples", cam8, world.intersect_device), ("surface-to-surface rays", inc, world.intersect_device),
                           ("surface-to-surface rays, static entry point", inc, world.intersect_device_static)):
     d_rays = hip_rt.DeviceBuffer.from_array(rays)
     d_hits = hip_rt.DeviceBuffer(rays.shape[0] * _lib.HIT_DTYPE.itemsize)

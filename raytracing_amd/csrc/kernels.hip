@@ -72,19 +72,21 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Batch closest hit (Shape::intersection_full for n rays).  Same lane scheduling as extend_kernel below: every wave
-// owns a contiguous slice of the batch, a lane whose ray has finished waits until a quarter of the wave is idle, then
-// the idle lanes write their hits and take the next rays of the slice, and every step the wave runs the phase (inner
-// node or primitive record) most of its busy lanes wait for.
-__global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const RayAoS *__restrict__ rays,
-                                                          HitAoS *__restrict__ hits, uint64_t n, uint32_t *spill) {
+// Batch closest hit (Shape::intersection_full for n rays).  Same lane scheduling as extend_kernel below: a lane whose
+// ray has finished waits until a quarter of the wave is idle, then the idle lanes write their hits and take the next
+// rays of the wave's share, and every step the wave runs the phase (inner node or primitive record) most of its busy
+// lanes wait for.  A wave's share is every `waves`-th chunk of 64 consecutive rays, not one contiguous slice: batches
+// come in the caller's order (camera rays row by row, say), the cost of a ray varies over the batch by orders of
+// magnitude, and a contiguous slice per wave leaves the waves of the cheap regions idle while the others work.
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void intersect_kernel(
+    SceneView scene, const RayAoS *__restrict__ rays, HitAoS *__restrict__ hits, uint64_t n, uint32_t *spill) {
     __shared__ uint32_t lds[LDS_STACK * BLOCK];
     LaneStack st = make_stack(lds, spill);
     const uint64_t waves = (uint64_t)gridDim.x * (BLOCK / 64);
     const uint64_t wave = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    const uint64_t per_wave = ((n + waves - 1) / waves + 63) / 64 * 64;
-    uint64_t next = wave * per_wave; // wave-uniform
-    const uint64_t end = next + per_wave < n ? next + per_wave : n;
+    const uint64_t chunks = (n + 63) / 64;
+    uint64_t next = 0; // wave-uniform position in the share: chunk next / 64 of this wave, ray next % 64 of it
+    const uint64_t end = chunks > wave ? (chunks - wave + waves - 1) / waves * 64 : 0;
     bool has_ray = false;
     uint64_t index = 0;
     float tnear = 0.0f;
@@ -119,9 +121,10 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(SceneView scene, const
             }
             if (next < end) {
                 const unsigned long long nmask = __ballot(!has_ray);
-                const uint64_t i = next + rank_in(nmask);
+                const uint64_t v = next + rank_in(nmask);
+                const uint64_t i = ((v >> 6) * waves + wave) * 64 + (v & 63);
                 next = next + (uint64_t)__popcll(nmask) < end ? next + (uint64_t)__popcll(nmask) : end;
-                if (!has_ray && i < end) {
+                if (!has_ray && v < end && i < n) {
                     const F4 *rp = reinterpret_cast<const F4 *>(rays + i);
                     const F4 r0 = rp[0], r1 = rp[1];
                     org = mk(r0.x, r0.y, r0.z);

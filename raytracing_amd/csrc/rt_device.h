@@ -84,6 +84,17 @@ RT_DEV const F4 *record_at(const SceneView &sv, uint32_t slot) {
     return reinterpret_cast<const F4 *>(reinterpret_cast<const char *>(sv.prims) + (slot << 6));
 }
 
+// Makes the compiler treat a loaded 16-byte word as used as a whole, right here.  Without it the record fetch of
+// test_prim, whose words are consumed on two sides of the sphere / triangle branch, is compiled to seven loads of
+// one to four dwords scattered over both sides instead of four 16-byte ones (measured: 2.5 % of a frame).
+RT_DEV void keep_whole(F4 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+#else
+    (void)v;
+#endif
+}
+
 struct CameraView {
     uint32_t width, height;
     float half_width, half_height, focal_length, aperture;
@@ -601,6 +612,10 @@ RT_DEV bool sphere_roots(V3 centre, float radius, V3 o, V3 d, float &t_front, fl
 RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnear, Closest &best) {
     const F4 *p = record_at(sv, slot);
     F4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+    keep_whole(r0);
+    keep_whole(r1);
+    keep_whole(r2);
+    keep_whole(r3);
     const uint32_t gidx0 = __builtin_bit_cast(uint32_t, r3.x), gidx1 = __builtin_bit_cast(uint32_t, r3.y);
     const uint32_t code = __builtin_bit_cast(uint32_t, r3.z);
     if (code & RT_SPHERE) {
