@@ -273,7 +273,7 @@ def make_roofline(args, device, world_scene, film, camera, info, profile, steps,
             row["hbm_bytes"] = c["rdreq"] * LINE_BYTES + c["write_kib"] * 1024.0
             row["gbs"] = row["hbm_bytes"] / row["ms"] / 1e6
             row["glines_per_s"] = c["rdreq"] / row["ms"] / 1e6
-            for k in ("l2_hit", "valu_busy", "lane_util", "ta_busy"):
+            for k in ("l2_hit", "valu_issue", "lane_util", "ta_busy"):
                 if k in c:
                     row[k] = c[k]
             tot_bytes += row["hbm_bytes"]
@@ -295,10 +295,12 @@ def make_roofline(args, device, world_scene, film, camera, info, profile, steps,
                          "ceiling_glines_per_s": LINE_RATE_CEILING / 1e9,
                          "frac": deep_lines / deep_ms / 1e6 / (LINE_RATE_CEILING / 1e9),
                          "ceiling_from": "profiles/r03_pmc/fetch_calib.txt (scattered 64-B and 128-B reads: 55.9 G lines/s)"}
-        shallow = [r for r in per_bounce if r["depth"] < 2 and "valu_busy" in r]
+        shallow = [r for r in per_bounce if r["depth"] < 2 and "valu_issue" in r]
         if shallow:
-            valu = {"bounces": "0 and 1 (instruction-issue-bound)",
-                    "valu_issue_frac": sum(r["valu_busy"] * r["ms"] for r in shallow) / sum(r["ms"] for r in shallow),
+            valu = {"bounces": "0 and 1",
+                    "valu_issue_frac_of": "the VALU wave instructions per SIMD and cycle of a pure v_fma_f32 stream "
+                                          "(0.431, profiles/r03_pmc/pk_fma_probe.txt)",
+                    "valu_issue_frac": sum(r["valu_issue"] * r["ms"] for r in shallow) / sum(r["ms"] for r in shallow),
                     "lane_util": sum(r["lane_util"] * r["ms"] for r in shallow) / sum(r["ms"] for r in shallow)}
         if tail and tj.get("tail") and tail["ms"] > 0:
             c = tj["tail"]
@@ -307,7 +309,7 @@ def make_roofline(args, device, world_scene, film, camera, info, profile, steps,
             tail["gbs"] = tail["hbm_bytes"] / tail["ms"] / 1e6
             tail["frac"] = tail["gbs"] / HBM_PEAK_GBS
             tail["glines_per_s"] = c["rdreq"] / tail["ms"] / 1e6
-            for k in ("l2_hit", "valu_busy", "lane_util", "ta_busy"):
+            for k in ("l2_hit", "valu_issue", "lane_util", "ta_busy"):
                 if k in c:
                     tail[k] = c[k]
     if tail:
@@ -333,9 +335,9 @@ def make_roofline(args, device, world_scene, film, camera, info, profile, steps,
         "kernel": "the traversal launches of a frame: extend_queue_kernel (bounces 0-1), extend_kernel (the bounces up to "
                   "the switch), tail_kernel (all later bounces in one launch)" if basis == "counters" else
                   "extend_kernel + extend_queue_kernel (the traversal launch of every wavefront bounce)",
-        "limited_by": "bounces 0-1: VALU issue at partial lane utilisation; deeper bounces: the rate at which the memory "
-                      "system completes scattered 128-byte line reads (line_rate below), of which a 64-byte node or record "
-                      "uses half",
+        "limited_by": "bounces 0-1: instruction issue (two thirds of the VALU rate of a pure multiply-add stream, at 0.67 "
+                      "lane utilisation); deeper bounces: that and the rate at which the memory system completes scattered "
+                      "128-byte line reads (line_rate below), of which a 64-byte node or record uses half",
         "launches_per_step": n_launch + (1 if tail and basis == "counters" else 0),
         "avg_launch_ms": (extend_ms / steps + (tail["ms"] if tail and basis == "counters" else 0.0)) /
                          (n_launch + (1 if tail and basis == "counters" else 0)),

@@ -11,8 +11,11 @@ Units.  TCC_EA0_RDREQ counts fabric read requests; one request is one 128-byte l
 bytes of it (profiles/r03_pmc/fetch_calib.txt: 1.00 requests per 128-byte line of a streaming read, 0.99 per
 scattered 64-byte record, 0.99 per scattered 128-byte record; FETCH_SIZE = requests x 64 B / 1024 on gfx950, i.e. half
 the bytes of the lines).  WRITE_SIZE is exact in KiB.  Memory-side bytes of a launch = requests x 128 + WRITE_SIZE x 1024.
-valu_busy = SQ_ACTIVE_INST_VALU x 4 / (cycles x 1024 SIMDs), lane_util = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64),
-cycles = GRBM_GUI_ACTIVE / 8 XCDs, l2_hit = TCC_HIT / TCC_REQ, ta_busy = TA_TA_BUSY / (256 CUs x cycles).
+valu_issue = SQ_INSTS_VALU / (cycles x 1024 SIMDs) / 0.431, the last being the wave instructions per SIMD and cycle a
+stream of independent v_fma_f32 reaches under the same two counters (profiles/r03_pmc/pk_fma_probe.txt; on this part
+SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU, so "x 4 cycles" says nothing about how busy the unit is);
+lane_util = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64), cycles = GRBM_GUI_ACTIVE / 8 XCDs,
+l2_hit = TCC_HIT / TCC_REQ, ta_busy = TA_TA_BUSY / (256 CUs x cycles).
 """
 import csv
 import glob
@@ -21,6 +24,8 @@ import os
 import shutil
 import sys
 from collections import defaultdict
+
+VALU_PEAK_PER_SIMD_CYCLE = 0.431  # 4295180288 v_fma_f32 in 77877008 / 8 cycles on 1024 SIMDs
 
 src, name = sys.argv[1], sys.argv[2]
 key = sys.argv[3] if len(sys.argv) > 3 else "dragon_1920x1080_100spp"
@@ -68,7 +73,7 @@ def derive(row):
     out["l2_hit"] = row["TCC_HIT_sum"] / max(row["TCC_REQ_sum"], 1.0)
     out["l1_accesses"] = row["TCP_TOTAL_CACHE_ACCESSES_sum"]
     out["ta_busy"] = row["TA_TA_BUSY_sum"] / (256.0 * cyc)
-    out["valu_busy"] = row["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
+    out["valu_issue"] = row["SQ_INSTS_VALU"] / (cyc * 1024.0) / VALU_PEAK_PER_SIMD_CYCLE
     out["lane_util"] = row["SQ_THREAD_CYCLES_VALU"] / max(row["SQ_ACTIVE_INST_VALU"] * 64.0, 1.0)
     out["valu_insts"] = row["SQ_INSTS_VALU"]
     out["salu_insts"] = row["SQ_INSTS_SALU"]
@@ -96,14 +101,14 @@ with open(os.path.join(here, name + "_pmc", "per_launch.txt"), "w") as fh:
     fh.write("one frame of %s (rocprofv3 --pmc, one pass per counter set; sources %s)\n" %
              (key, open(os.path.join(src, "csrc_hash.txt")).read().strip()))
     hdr = "%-22s %5s %8s %9s %7s %9s %8s %8s %8s %9s %9s %8s %8s %8s\n" % (
-        "kernel", "depth", "Mcycles", "lines(M)", "l2_hit", "l2_req(M)", "ta_busy", "hbm(GB)", "write(GB)", "valu_busy",
+        "kernel", "depth", "Mcycles", "lines(M)", "l2_hit", "l2_req(M)", "ta_busy", "hbm(GB)", "write(GB)", "valu_issue",
         "lane_util", "valu(G)", "wait_any", "wait_inst")
     fh.write(hdr)
     for group in (extend, tail, shade, others["raygen_kernel"], others["accumulate_kernel"]):
         for i, r in enumerate(group):
             fh.write("%-22s %5s %8.2f %9.1f %7.2f %9.1f %8.2f %8.2f %8.2f %9.2f %9.2f %8.2f %8.2f %8.2f\n" % (
                 r["kernel"], r.get("depth", i), r["mcycles"], r["rdreq"] / 1e6, r["l2_hit"], r["l2_req"] / 1e6, r["ta_busy"],
-                r["hbm_bytes"] / 1e9, r["write_kib"] * 1024 / 1e9, r["valu_busy"], r["lane_util"], r["valu_insts"] / 1e9,
+                r["hbm_bytes"] / 1e9, r["write_kib"] * 1024 / 1e9, r["valu_issue"], r["lane_util"], r["valu_insts"] / 1e9,
                 r["wait_any"], r["wait_inst"]))
     fh.write("frame: traversal launches %.1f GB memory-side (%.2f G lines), tail %.1f GB, shading %.1f GB\n" % (
         sum(r["hbm_bytes"] for r in extend) / 1e9, sum(r["rdreq"] for r in extend) / 1e9,
@@ -111,7 +116,7 @@ with open(os.path.join(here, name + "_pmc", "per_launch.txt"), "w") as fh:
 
 tfile = os.path.join(here, "traffic.json")
 tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
-keep = ("kernel", "depth", "rdreq", "fetch_kib", "write_kib", "l2_hit", "valu_busy", "lane_util", "ta_busy", "hbm_bytes")
+keep = ("kernel", "depth", "rdreq", "fetch_kib", "write_kib", "l2_hit", "valu_issue", "lane_util", "ta_busy", "hbm_bytes")
 tj[key] = {
     "csrc_sha256": open(os.path.join(src, "csrc_hash.txt")).read().strip(),
     "from": "profiles/%s_pmc/per_launch.txt (profiles/collect.sh + profiles/make_traffic.py)" % name,

@@ -95,6 +95,32 @@ RT_DEV void keep_whole(F4 &v) {
 #endif
 }
 
+// Conditions and selects.  For `c ? a : b` the compiler emits v_cndmask_b32 with the condition in vcc, and a wave that
+// issues two of those in a row waits some fifteen cycles for the second (measured, profiles/experiments/
+// pk_fma_probe.hip: runs of selects on vcc issue at a quarter of the rate of the same selects on a scalar register
+// pair); traversal code is full of such runs (near / far planes, sorting network, best-candidate update).  So the hot
+// code keeps its conditions as lane masks in scalar registers -- lanes(c), combined with & and | on the scalar unit --
+// and selects through them.  On the host a lane mask is a bool.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned long long LaneMask;
+RT_DEV LaneMask lanes(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+RT_DEV float select(LaneMask m, float a, float b) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+RT_DEV uint32_t select(LaneMask m, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+#else
+typedef bool LaneMask;
+RT_DEV LaneMask lanes(bool c) { return c; }
+RT_DEV float select(LaneMask m, float a, float b) { return m ? a : b; }
+RT_DEV uint32_t select(LaneMask m, uint32_t a, uint32_t b) { return m ? a : b; }
+#endif
+
 struct CameraView {
     uint32_t width, height;
     float half_width, half_height, focal_length, aperture;
@@ -543,19 +569,18 @@ struct Closest {
 
 // Candidate order: smaller t wins, equal t goes to the smaller global primitive index, so the result is the same
 // for every traversal order.
-RT_DEV void take_candidate(float t, uint32_t gidx, uint32_t slot, float u, float v, bool ok, Closest &best) {
-    if (ok && (t < best.t || (t == best.t && gidx < best.gidx))) {
-        best.t = t;
-        best.gidx = gidx;
-        best.slot = slot;
-        best.u = u;
-        best.v = v;
-    }
+RT_DEV void take_candidate(float t, uint32_t gidx, uint32_t slot, float u, float v, LaneMask ok, Closest &best) {
+    const LaneMask take = ok & (lanes(t < best.t) | (lanes(t == best.t) & lanes(gidx < best.gidx)));
+    best.t = select(take, t, best.t);
+    best.gidx = select(take, gidx, best.gidx);
+    best.slot = select(take, slot, best.slot);
+    best.u = select(take, u, best.u);
+    best.v = select(take, v, best.v);
 }
 
 // Moeller-Trumbore, no culling; edges inclusive; NaNs reject.  Written without early exits (lanes of a wave rarely
 // agree on them); every value is the one the exiting form would have computed.
-RT_DEV bool tri_test(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float tnear, float &t, float &u, float &v) {
+RT_DEV LaneMask tri_test(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float tnear, float &t, float &u, float &v) {
     V3 pv = cross(d, e2);
     float det = dot(e1, pv);
     float inv = 1.0f / det;
@@ -564,14 +589,14 @@ RT_DEV bool tri_test(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float tnear, float &t, flo
     V3 q = cross(tv, e1);
     v = dot(d, q) * inv;
     t = dot(e2, q) * inv;
-    return (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) && (t > tnear);
+    return lanes(det != 0.0f) & lanes(u >= 0.0f) & lanes(u <= 1.0f) & lanes(v >= 0.0f) & lanes(u + v <= 1.0f) & lanes(t > tnear);
 }
 
 RT_DEV V3 select_corner(uint32_t s, V3 a, V3 b, V3 c, V3 d) {
-    const bool odd = (s & 1u) != 0u, high = (s & 2u) != 0u;
-    V3 lo = mk(odd ? b.x : a.x, odd ? b.y : a.y, odd ? b.z : a.z);
-    V3 hi = mk(odd ? d.x : c.x, odd ? d.y : c.y, odd ? d.z : c.z);
-    return mk(high ? hi.x : lo.x, high ? hi.y : lo.y, high ? hi.z : lo.z);
+    const LaneMask odd = lanes((s & 1u) != 0u), high = lanes((s & 2u) != 0u);
+    V3 lo = mk(select(odd, b.x, a.x), select(odd, b.y, a.y), select(odd, b.z, a.z));
+    V3 hi = mk(select(odd, d.x, c.x), select(odd, d.y, c.y), select(odd, d.z, c.z));
+    return mk(select(high, hi.x, lo.x), select(high, hi.y, lo.y), select(high, hi.z, lo.z));
 }
 
 // Corners of triangle `which` (0 or 1) of a record, in the triangle's own vertex order.
@@ -629,7 +654,7 @@ RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnea
             t = t_back;
         else
             return;
-        take_candidate(t, gidx0, 2u * slot, 0.0f, 0.0f, true, best);
+        take_candidate(t, gidx0, 2u * slot, 0.0f, 0.0f, lanes(true), best);
         return;
     }
     // one triangle after the other: letting the compiler interleave the two tests costs ~20 registers, and the
@@ -638,7 +663,7 @@ RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnea
         V3 v0, v1, v2;
         record_corners(r0, r1, r2, code, 0u, v0, v1, v2);
         float t, u, v;
-        const bool ok = tri_test(v0, sub(v1, v0), sub(v2, v0), o, d, tnear, t, u, v);
+        const LaneMask ok = tri_test(v0, sub(v1, v0), sub(v2, v0), o, d, tnear, t, u, v);
         take_candidate(t, gidx0, 2u * slot, u, v, ok, best);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -648,7 +673,7 @@ RT_DEV void test_prim(const SceneView &sv, uint32_t slot, V3 o, V3 d, float tnea
         V3 v0, v1, v2;
         record_corners(r0, r1, r2, code, 1u, v0, v1, v2);
         float t, u, v;
-        const bool ok = tri_test(v0, sub(v1, v0), sub(v2, v0), o, d, tnear, t, u, v) && gidx1 != RT_EMPTY;
+        const LaneMask ok = tri_test(v0, sub(v1, v0), sub(v2, v0), o, d, tnear, t, u, v) & lanes(gidx1 != RT_EMPTY);
         take_candidate(t, gidx1, 2u * slot + 1u, u, v, ok, best);
     }
 }
@@ -724,12 +749,13 @@ RT_DEV void trav_node_step(const SceneView &sv, float tnear, Trav &tr, Stack &st
     const float by = __builtin_fmaf(__builtin_bit_cast(float, w0.y), tr.iy, tr.noy);
     const float bz = __builtin_fmaf(__builtin_bit_cast(float, w0.z), tr.iz, tr.noz);
     // the plane a ray meets first on an axis is the low one when it travels in the positive direction
-    const bool nx = tr.ix < 0.0f, ny = tr.iy < 0.0f, nz = tr.iz < 0.0f;
-    const uint32_t qnx = nx ? w2.y : w1.z, qfx = nx ? w1.z : w2.y;
-    const uint32_t qny = ny ? w2.z : w1.w, qfy = ny ? w1.w : w2.z;
-    const uint32_t qnz = nz ? w2.w : w2.x, qfz = nz ? w2.x : w2.w;
+    const LaneMask nx = lanes(tr.ix < 0.0f), ny = lanes(tr.iy < 0.0f), nz = lanes(tr.iz < 0.0f);
+    const uint32_t qnx = select(nx, w2.y, w1.z), qfx = select(nx, w1.z, w2.y);
+    const uint32_t qny = select(ny, w2.z, w1.w), qfy = select(ny, w1.w, w2.z);
+    const uint32_t qnz = select(nz, w2.w, w2.x), qfz = select(nz, w2.x, w2.w);
     const float tfar = tr.best.t;
     float tn[4];
+    LaneMask hit[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int sh = 8 * k;
@@ -741,24 +767,24 @@ RT_DEV void trav_node_step(const SceneView &sv, float tnear, Trav &tr, Stack &st
         const float t1z = __builtin_fmaf((float)((qfz >> sh) & 255u), sz, bz);
         const float tmin = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, tnear));
         const float tmax = fminf(fminf(t1x, t1y), fminf(t1z, tfar));
-        const bool hit = (ch[k] != RT_EMPTY) && (tmin <= tmax * 1.0000004f);
-        tn[k] = hit ? tmin : INFINITY;
+        hit[k] = lanes(ch[k] != RT_EMPTY) & lanes(tmin <= tmax * 1.0000004f);
+        tn[k] = select(hit[k], tmin, INFINITY);
     }
     // 4-element sorting network on (entry distance, child), nearest first; misses carry +inf and RT_EMPTY
     float a0 = tn[0], a1 = tn[1], a2 = tn[2], a3 = tn[3];
-    uint32_t i0 = a0 < INFINITY ? ch[0] : RT_EMPTY, i1 = a1 < INFINITY ? ch[1] : RT_EMPTY;
-    uint32_t i2 = a2 < INFINITY ? ch[2] : RT_EMPTY, i3 = a3 < INFINITY ? ch[3] : RT_EMPTY;
-#define RT_CSWAP(ta, ia, tb, ib)          \
-    {                                     \
-        bool sw = tb < ta;                \
-        float tlo = sw ? tb : ta;         \
-        float thi = sw ? ta : tb;         \
-        uint32_t ilo = sw ? ib : ia;      \
-        uint32_t ihi = sw ? ia : ib;      \
-        ta = tlo;                         \
-        tb = thi;                         \
-        ia = ilo;                         \
-        ib = ihi;                         \
+    uint32_t i0 = select(hit[0], ch[0], RT_EMPTY), i1 = select(hit[1], ch[1], RT_EMPTY);
+    uint32_t i2 = select(hit[2], ch[2], RT_EMPTY), i3 = select(hit[3], ch[3], RT_EMPTY);
+#define RT_CSWAP(ta, ia, tb, ib)               \
+    {                                          \
+        const LaneMask sw = lanes(tb < ta);    \
+        const float tlo = select(sw, tb, ta);  \
+        const float thi = select(sw, ta, tb);  \
+        const uint32_t ilo = select(sw, ib, ia); \
+        const uint32_t ihi = select(sw, ia, ib); \
+        ta = tlo;                              \
+        tb = thi;                              \
+        ia = ilo;                              \
+        ib = ihi;                              \
     }
     RT_CSWAP(a0, i0, a1, i1)
     RT_CSWAP(a2, i2, a3, i3)
