@@ -236,8 +236,7 @@ struct Builder {
 
 } // namespace
 
-bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool(double)> &progress, unsigned threads,
-           Layout layout) {
+bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool(double)> &progress, unsigned threads) {
     out = WideBvh();
     const size_t n = boxes.size();
     if (progress && !progress(0.0)) return false;
@@ -283,7 +282,6 @@ bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool
     std::vector<rtd::F4> W; // the nodes, breadth-first, child references by breadth-first index / leaf slot
     std::vector<uint8_t> nchild;
     std::vector<uint32_t> child_ref; // 4 per wide node
-    std::vector<float> child_area;   // 4 per wide node: half area of the child's box (-1 = no child)
     const float root_area = half_area(N2[0].box);
     double sah = 0.0;
     for (size_t w = 0; w < wide_root.size(); ++w) {
@@ -375,10 +373,7 @@ bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool
         memcpy(&f[12], refs, sizeof refs);
         for (int k = 0; k < rtd::RT_NODE_F4; ++k) W.push_back(slots[k]);
         nchild.push_back((uint8_t)nc);
-        for (int k = 0; k < 4; ++k) {
-            child_ref.push_back(refs[k]);
-            child_area.push_back(k < nc ? half_area(N2[ch[k]].box) : -1.0f);
-        }
+        for (int k = 0; k < 4; ++k) child_ref.push_back(refs[k]);
         if (progress && (w & 0xFFFF) == 0 && !progress(0.8 + 0.1 * (double)w / (double)(wide_root.size() + 1)))
             return false;
     }
@@ -407,84 +402,57 @@ bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool
     out.stack_need = need[0];
     out.depth = depth[0];
 
-    // ---- placement: item index of every node and of every leaf slot
+    // ---- placement: the children of a node, inner nodes and records alike, take consecutive items in slot order, so
+    // that the node names them by one index (and siblings, which a ray that reaches the node tends to visit together,
+    // share lines).  Groups go breadth-first and start on a line boundary; the root has the first line to itself.
+    static_assert(LEAF_MAX == 1, "a leaf is one record: child k of a node is item first + k");
     const uint32_t n_nodes = out.n_nodes, n_slots = (uint32_t)n;
-    std::vector<uint32_t> node_item(n_nodes, rtd::RT_EMPTY), rec_item(n_slots, rtd::RT_EMPTY);
-    uint32_t next = 0;
-    if (layout == Layout::BFS || LEAF_MAX != 1) {
-        for (uint32_t w = 0; w < n_nodes; ++w) node_item[w] = w;
-        const uint32_t base = (n_nodes + 1u) & ~1u;
-        for (uint32_t s = 0; s < n_slots; ++s) rec_item[s] = base + s;
-        next = (base + n_slots + 1u) & ~1u;
-    } else {
-        // Lines (pairs of items) in breadth-first order of their first item.  A line is headed by a node, whose
-        // largest child takes the other half; the children of both halves that are left over head lines of their own
-        // (nodes) or share lines two by two (records).
-        struct Head {
-            uint32_t a, b; // node: a = breadth-first index, b = RT_EMPTY - 1; records: leaf slots a and b (b may be RT_EMPTY)
-        };
-        constexpr uint32_t IS_NODE = rtd::RT_EMPTY - 1u;
-        std::vector<Head> heads;
-        heads.reserve((size_t)n_nodes + n_slots / 2 + 16);
-        heads.push_back(Head{0u, IS_NODE});
-        for (size_t i = 0; i < heads.size(); ++i) {
-            const Head h = heads[i];
-            if (h.b != IS_NODE) {
-                rec_item[h.a] = next;
-                if (h.b != rtd::RT_EMPTY) rec_item[h.b] = next + 1u;
-                next += 2u;
-                continue;
-            }
-            const uint32_t w = h.a;
-            node_item[w] = next;
-            int fav = 0;
-            for (int k = 1; k < 4; ++k)
-                if (child_area[4 * (size_t)w + k] > child_area[4 * (size_t)w + fav]) fav = k;
-            uint32_t nodes_left[8], recs_left[8];
-            int nn = 0, nr = 0;
-            const uint32_t tail = child_ref[4 * (size_t)w + fav];
-            if (tail & rtd::RT_LEAF) {
-                rec_item[tail & 0x0FFFFFFFu] = next + 1u;
-            } else {
-                node_item[tail] = next + 1u;
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t c = child_ref[4 * (size_t)tail + k];
-                    if (c == rtd::RT_EMPTY) continue;
-                    if (c & rtd::RT_LEAF)
-                        recs_left[nr++] = c & 0x0FFFFFFFu;
-                    else
-                        nodes_left[nn++] = c;
-                }
-            }
-            next += 2u;
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t c = child_ref[4 * (size_t)w + k];
-                if (c == rtd::RT_EMPTY || k == fav) continue;
-                if (c & rtd::RT_LEAF)
-                    recs_left[nr++] = c & 0x0FFFFFFFu;
-                else
-                    nodes_left[nn++] = c;
-            }
-            for (int k = 0; k < nn; ++k) heads.push_back(Head{nodes_left[k], IS_NODE});
-            for (int k = 0; k < nr; k += 2) heads.push_back(Head{recs_left[k], k + 1 < nr ? recs_left[k + 1] : rtd::RT_EMPTY});
+    std::vector<uint32_t> node_item(n_nodes, rtd::RT_EMPTY), rec_item(n_slots, rtd::RT_EMPTY), first_item(n_nodes, 0);
+    uint32_t next = 2;
+    if (n_nodes > 0) node_item[0] = 0;
+    for (uint32_t w = 0; w < n_nodes; ++w) { // a parent has a smaller breadth-first index than its children
+        const uint32_t nc = nchild[w];
+        first_item[w] = next;
+        for (uint32_t k = 0; k < nc; ++k) {
+            const uint32_t c = child_ref[4 * (size_t)w + k];
+            if (c & rtd::RT_LEAF)
+                rec_item[c & 0x0FFFFFFFu] = next + k;
+            else
+                node_item[c] = next + k;
         }
+        next = (next + nc + 1u) & ~1u;
     }
     out.n_items = next;
     out.items.assign((size_t)next * rtd::RT_NODE_F4, rtd::F4{0.0f, 0.0f, 0.0f, 0.0f});
     for (uint32_t w = 0; w < n_nodes; ++w) {
-        uint32_t refs[4];
-        for (int k = 0; k < 4; ++k) {
+        // W[w] holds origin, steps, planes and the breadth-first child refs; the item gets the packed form the kernels
+        // read (rt_device.h) in its first 48 bytes and the children's item refs, one word each, in the last 16
+        const float *src = reinterpret_cast<const float *>(&W[(size_t)w * rtd::RT_NODE_F4]);
+        uint32_t word[16];
+        memcpy(word, src, 64);
+        uint32_t step_hi[3];
+        for (int a = 0; a < 3; ++a) step_hi[a] = word[3 + a] >> 16; // a power of two: the low 16 bits are zero
+        uint32_t leaf_bits = 0, refs[4];
+        const uint32_t nc = nchild[w];
+        for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t c = child_ref[4 * (size_t)w + k];
-            if (c == rtd::RT_EMPTY)
+            if (c == rtd::RT_EMPTY) {
                 refs[k] = c;
-            else if (c & rtd::RT_LEAF)
-                refs[k] = (c & 0xF0000000u) | rec_item[c & 0x0FFFFFFFu];
-            else
-                refs[k] = node_item[c];
+            } else if (c & rtd::RT_LEAF) {
+                leaf_bits |= 1u << k;
+                refs[k] = rtd::RT_LEAF | (first_item[w] + k);
+            } else {
+                refs[k] = first_item[w] + k;
+            }
         }
-        rtd::F4 *dst = &out.items[(size_t)node_item[w] * rtd::RT_NODE_F4];
-        memcpy(dst, &W[(size_t)w * rtd::RT_NODE_F4], 64);
-        memcpy(reinterpret_cast<float *>(dst) + 12, refs, sizeof refs);
+        uint32_t item[16];
+        memcpy(&item[0], &word[0], 12);                 // origin
+        item[3] = step_hi[0] | (step_hi[1] << 16);      // steps x, y
+        memcpy(&item[4], &word[6], 24);                 // planes
+        item[10] = step_hi[2] | (leaf_bits << 16) | ((nc - 1u) << 24);
+        item[11] = first_item[w];
+        memcpy(&item[12], refs, sizeof refs);
+        memcpy(&out.items[(size_t)node_item[w] * rtd::RT_NODE_F4], item, 64);
     }
     out.record_item = std::move(rec_item);
     if (progress && !progress(0.9)) return false;

@@ -1,5 +1,5 @@
 // bvh.h -- host-side acceleration structure build for the GPU kernels: binned-SAH binary BVH over padded primitive
-// boxes, collapsed to 4-wide nodes in the 64-byte quantised node layout of rt_device.h, and laid out together with the
+// boxes, collapsed to 4-wide nodes in the quantised node layout of rt_device.h (48 bytes in a 64-byte item), and laid out together with the
 // 64-byte slots of the primitive records in ONE array of 64-byte items (a 128-byte line, the unit the memory system
 // fetches, holds two of them).
 // Stands in for what rtcCommitScene does inside Embree for the reference (crates/rt/src/aggregate/embree.rs:63-69).
@@ -19,16 +19,11 @@ struct Box {
     float lo[3], hi[3];
 };
 
-// How nodes and record slots are placed in the item array.
-//   BFS    all nodes breadth-first, then all record slots in leaf order: the inner children of a node are neighbours,
-//          so siblings often share a line.  The default.
-//   PAIRS  every 128-byte line holds a node and its largest child (an inner node or a record: the child a ray that
-//          reaches the node is most likely to visit), or two leftover records of one parent; lines breadth-first.
-//          Measured on a 5 M-triangle mesh: 6-7 % fewer lines fetched from beyond L2 per incoherent ray, 1 % more L2
-//          requests, 14 % more memory, and no time gained (the traversal kernel is bound by instruction issue and
-//          by the L1 address path at that point), hence not the default.
-enum class Layout { BFS, PAIRS };
-
+// Placement in the item array: the children of a node (inner nodes and the records of its leaves) take consecutive
+// items in slot order, groups breadth-first, every group starting on a 128-byte line; a node names its children by the
+// index of the first.  (A placement that put every node next to its largest child, and records two by two, fetched
+// 6-7 % fewer lines from beyond L2 per incoherent ray on a 5 M-triangle mesh and gained no time; it is gone with the
+// per-child references it needed.)
 struct WideBvh {
     std::vector<rtd::F4> items;        // n_items x RT_NODE_F4: nodes in place (root = item 0), record slots zeroed
     std::vector<uint32_t> prim_order;  // leaf slot -> index of the input primitive
@@ -43,6 +38,6 @@ struct WideBvh {
 // boxes: one padded box per primitive.  progress(amount in [0,1]) returning false cancels; build() then returns
 // false.  threads = worker threads for subtree builds (0 = hardware concurrency, capped at 16).
 bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool(double)> &progress,
-           unsigned threads = 0, Layout layout = Layout::BFS);
+           unsigned threads = 0);
 
 } // namespace rtb

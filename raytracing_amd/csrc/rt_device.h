@@ -30,10 +30,16 @@ namespace rtd {
 
 // ---------------------------------------------------------------------------------------------- layout
 
-// 64-byte BVH4 node, 16 words: origin.xyz, step.xyz (f32), six words of 8-bit child planes (lo.x, lo.y, lo.z, hi.x,
-// hi.y, hi.z; child k in byte k; plane = origin + q * step, rounded outwards at build time), four child refs.
-// Child ref: RT_EMPTY = unused slot; bit 31 set = leaf: bits 28..30 = prim count - 1, bits 0..27 = first prim slot;
-// otherwise the index of an inner node.
+// BVH4 node: a 64-byte item of which the kernels read the first 48 bytes (three 16-byte loads instead of four: the
+// traversal kernels are bound by the vector memory pipeline on incoherent rays, where one more 16-byte load per node
+// step measured +20-25 %).  Words: 0-2 origin.xyz; 3 = the upper halves of step.x | step.y << 16 (steps are powers of
+// two, so the upper half of the float is the float); 4-9 six words of 8-bit child planes (lo.x, lo.y, lo.z, hi.x, hi.y,
+// hi.z; child k in byte k; plane = origin + q * step, rounded outwards at build time); 10 = upper half of step.z |
+// leaf bits << 16 (bit k: child k is a leaf) | (children - 1) << 24; 11 = item index of child 0, child k being item
+// first + k (the children of a node are neighbours in the item array, and fill slots 0 .. children - 1).  Words 12-15
+// repeat the four child refs in the form below for host-side tools; no kernel reads them.
+// Child ref (traversal stack entries, Trav::cur): RT_EMPTY = none; bit 31 set = leaf: bits 28..30 = records - 1,
+// bits 0..27 = item of the first record; otherwise the item index of an inner node.
 struct alignas(16) F4 {
     float x, y, z, w;
 };
@@ -739,20 +745,25 @@ RT_DEV void trav_begin(const SceneView &sv, V3 o, V3 d, float tfar, Trav &tr) {
 template <class Stack>
 RT_DEV void trav_node_step(const SceneView &sv, float tnear, Trav &tr, Stack &st) {
     const U4 *n = node_at(sv, tr.cur);
-    const U4 w0 = n[0], w1 = n[1], w2 = n[2], w3 = n[3];
-    const uint32_t ch[4] = {w3.x, w3.y, w3.z, w3.w};
+    const U4 w0 = n[0], w1 = n[1], w2 = n[2];
+    const uint32_t meta = w2.z, first = w2.w;
+    // child k as (leaf bit | k): the item index is added once the children are ordered
+    const uint32_t ch[4] = {((meta << 15) & RT_LEAF) | 0u, ((meta << 14) & RT_LEAF) | 1u, ((meta << 13) & RT_LEAF) | 2u,
+                            ((meta << 12) & RT_LEAF) | 3u};
+    const uint32_t last = (meta >> 24) & 3u; // children - 1
     // plane distance = (origin + q * step - o) / d = q * (step / d) + (origin / d - o / d)
-    const float sx = __builtin_bit_cast(float, w0.w) * tr.ix;
-    const float sy = __builtin_bit_cast(float, w1.x) * tr.iy;
-    const float sz = __builtin_bit_cast(float, w1.y) * tr.iz;
+    const float sx = __builtin_bit_cast(float, w0.w << 16) * tr.ix;
+    const float sy = __builtin_bit_cast(float, w0.w & 0xFFFF0000u) * tr.iy;
+    const float sz = __builtin_bit_cast(float, meta << 16) * tr.iz;
     const float bx = __builtin_fmaf(__builtin_bit_cast(float, w0.x), tr.ix, tr.nox);
     const float by = __builtin_fmaf(__builtin_bit_cast(float, w0.y), tr.iy, tr.noy);
     const float bz = __builtin_fmaf(__builtin_bit_cast(float, w0.z), tr.iz, tr.noz);
     // the plane a ray meets first on an axis is the low one when it travels in the positive direction
     const LaneMask nx = lanes(tr.ix < 0.0f), ny = lanes(tr.iy < 0.0f), nz = lanes(tr.iz < 0.0f);
-    const uint32_t qnx = select(nx, w2.y, w1.z), qfx = select(nx, w1.z, w2.y);
-    const uint32_t qny = select(ny, w2.z, w1.w), qfy = select(ny, w1.w, w2.z);
-    const uint32_t qnz = select(nz, w2.w, w2.x), qfz = select(nz, w2.x, w2.w);
+    const uint32_t qnx = select(nx, w1.w, w1.x), qfx = select(nx, w1.x, w1.w);
+    const uint32_t qny = select(ny, w2.x, w1.y), qfy = select(ny, w1.y, w2.x);
+    const uint32_t qnz = select(nz, w2.y, w1.z), qfz = select(nz, w1.z, w2.y);
+    const LaneMask exists[4] = {lanes(true), lanes(last >= 1u), lanes(last >= 2u), lanes(last >= 3u)};
     const float tfar = tr.best.t;
     float tn[4];
     LaneMask hit[4];
@@ -767,7 +778,7 @@ RT_DEV void trav_node_step(const SceneView &sv, float tnear, Trav &tr, Stack &st
         const float t1z = __builtin_fmaf((float)((qfz >> sh) & 255u), sz, bz);
         const float tmin = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, tnear));
         const float tmax = fminf(fminf(t1x, t1y), fminf(t1z, tfar));
-        hit[k] = lanes(ch[k] != RT_EMPTY) & lanes(tmin <= tmax * 1.0000004f);
+        hit[k] = exists[k] & lanes(tmin <= tmax * 1.0000004f);
         tn[k] = select(hit[k], tmin, INFINITY);
     }
     // 4-element sorting network on (entry distance, child), nearest first; misses carry +inf and RT_EMPTY
@@ -795,10 +806,10 @@ RT_DEV void trav_node_step(const SceneView &sv, float tnear, Trav &tr, Stack &st
     if (i0 == RT_EMPTY) {
         tr.cur = st.empty() ? RT_EMPTY : st.pop();
     } else {
-        if (i3 != RT_EMPTY) st.push(i3);
-        if (i2 != RT_EMPTY) st.push(i2);
-        if (i1 != RT_EMPTY) st.push(i1);
-        tr.cur = i0;
+        if (i3 != RT_EMPTY) st.push(first + i3);
+        if (i2 != RT_EMPTY) st.push(first + i2);
+        if (i1 != RT_EMPTY) st.push(first + i1);
+        tr.cur = first + i0;
     }
 }
 

@@ -227,10 +227,7 @@ bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, size_t *
         if (prims[i].geom >= geom_first.size()) geom_first.resize(prims[i].geom + 1, NONE);
         if (geom_first[prims[i].geom] == NONE) geom_first[prims[i].geom] = (uint32_t)i;
     }
-    rtb::Layout layout = rtb::Layout::BFS;
-    if (const char *v = getenv("RTMI_LAYOUT"))
-        if (strcmp(v, "pairs") == 0) layout = rtb::Layout::PAIRS;
-    if (!rtb::build(rec_boxes, bvh, progress, 0, layout)) return false;
+    if (!rtb::build(rec_boxes, bvh, progress, 0)) return false;
     if (n_records) *n_records = nr;
     for (size_t slot = 0; slot < nr; ++slot) {
         const uint32_t i = rec_first[bvh.prim_order[slot]], j = mate[i];

@@ -21,8 +21,7 @@ void apply_transform(const float translation[3], const float scale[3], const flo
 // Pairs triangles into records, builds the BVH over the records (global primitive index = position in `prims`;
 // the primitives of one geometry must be consecutive) and writes every record into the item array of the tree
 // (bvh.items) at the place the tree's layout gives its leaf.  lo/hi receive the unpadded scene bounds; *n_records the
-// number of records.  Returns false when the progress callback cancels.  The environment variable RTMI_LAYOUT=pairs
-// selects the paired placement (rtb::Layout::PAIRS) for comparisons; results never depend on the placement.
+// number of records.  Returns false when the progress callback cancels.
 bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, size_t *n_records, float lo[3], float hi[3],
                  const std::function<bool(double)> &progress);
 

@@ -162,25 +162,6 @@ def test_accumulators_bit_equal_to_oracle(oracle, scene_classes, device, monkeyp
     assert eq.all(), "%d of %d accumulator words differ" % ((~eq).sum(), eq.size)
 
 
-@pytest.mark.parametrize("name,size,spp,kw", [("cornell-box", (160, 90), 5, {}), ("dragon", (128, 72), 6, {"levels": 3})])
-def test_paired_item_layout_bit_equal_to_oracle(oracle, scene_classes, device, monkeypatch, name, size, spp, kw):
-    """RTMI_LAYOUT=pairs (a node and its largest child share a 128-byte line, csrc/bvh.h) against the default
-    breadth-first placement: the same accumulators, ray counts and closest hits."""
-    monkeypatch.setenv("RTMI_LAYOUT", "pairs")
-    so, world = build_pair(oracle, scene_classes[name], device, **kw)
-    monkeypatch.delenv("RTMI_LAYOUT")
-    for tail_rays in ("0", None):
-        if tail_rays is not None:
-            monkeypatch.setenv("RTMI_TAIL_RAYS", tail_rays)
-        else:
-            monkeypatch.delenv("RTMI_TAIL_RAYS")
-        got, st, want, want_rays = render_both(oracle, so, world, device, size[0], size[1], spp)
-        assert st["rays"] == want_rays
-        assert same_bits(got, want).all()
-    rays = primary_rays(oracle, so, 320, 180, jitter_sample=1)
-    check_hits(world.intersect(rays), so.intersect(rays, oracle.ISECT_BVH))
-
-
 @pytest.mark.parametrize("name,size,spp,kw", [("cornell-box", (160, 90), 5, {}), ("dragon", (128, 72), 6, {"levels": 2}),
                                               ("spheres", (160, 90), 9, {})])
 @pytest.mark.parametrize("queue_depths", ["0", "99"])

@@ -199,27 +199,6 @@ def test_device_code_on_host_matches_oracle(oracle, hostsim, scene_classes, name
     assert sh.stack_high() <= sh.info["stack_need"] <= 128
 
 
-@pytest.mark.parametrize("name,kw", [("cornell-box", {}), ("bunny", {}), ("dragon", {"levels": 1})])
-def test_paired_item_layout_changes_no_result(oracle, hostsim, scene_classes, monkeypatch, name, kw):
-    """RTMI_LAYOUT=pairs places every node next to its largest child in the item array (csrc/bvh.h).  Placement is not
-    allowed to change a bit: the same tree, the same hits, the same accumulators as the oracle."""
-    from raytracing_amd import types
-    monkeypatch.setenv("RTMI_LAYOUT", "pairs")
-    so, sh = build_both(oracle, hostsim, scene_classes[name], **kw)
-    monkeypatch.delenv("RTMI_LAYOUT")
-    _, sh_bfs = build_both(oracle, hostsim, scene_classes[name], **kw)
-    assert sh.info["n_nodes"] == sh_bfs.info["n_nodes"] and sh.info["stack_need"] == sh_bfs.info["stack_need"]
-    W, H = 96, 54
-    cam = types.Camera.from_dimensions(W, H)
-    xy = full_frame_xy(W, H)
-    rays = so.camera_rays(cam, oracle.make_params(spp=1), xy, 0)
-    rays["tnear"] = 1e-5
-    assert sh.intersect(rays).tobytes() == so.intersect(rays, oracle.ISECT_BVH).tobytes()
-    acc_o, rays_o = so.render(cam, oracle.make_params(spp=2), xy)
-    acc_h, rays_h = sh.render(cam, hostsim.params(spp=2), xy)
-    assert rays_o == rays_h and same_bits(acc_o, acc_h).all()
-
-
 @pytest.mark.parametrize("aperture", [0.0, 0.1])
 def test_optics_lab_on_host_matches_oracle(oracle, hostsim, aperture):
     """Thin dielectric, smooth dielectric, ior == 1 and the thin-lens, rotated camera: the device code built for the
