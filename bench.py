@@ -332,7 +332,7 @@ def make_roofline(args, device, world_scene, film, camera, info, profile, steps,
                       "their time, measured live" if basis == "counters" else
                       "ALGORITHMIC bytes (no counter file for this build and workload%s): prices bytes L2 serves against "
                       "HBM and can exceed 1" % ("; " + stale if stale else ""),
-        "kernel": "the traversal launches of a frame: extend_queue_kernel (bounces 0-1), extend_kernel (the bounces up to "
+        "kernel": "the traversal launches of a frame: extend_queue_kernel (bounces 0-2), extend_kernel (the bounces up to "
                   "the switch), tail_kernel (all later bounces in one launch)" if basis == "counters" else
                   "extend_kernel + extend_queue_kernel (the traversal launch of every wavefront bounce)",
         "limited_by": "bounces 0-1: instruction issue (two thirds of the VALU rate of a pure multiply-add stream, at 0.67 "

@@ -831,14 +831,15 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     a.seed = params->seed;
 
     a.allowed_error = adaptive ? params->allowed_error : 0.0f;
-    a.refill_below = 48;
+    a.refill_below = 40; // swept 32 .. 56 on 5 M triangles: flat from 32 to 40, 3 % slower on deep bounces at 48
     a.leaf_bias = 0;
     if (const char *v = getenv("RTMI_REFILL_BELOW")) a.refill_below = atoi(v);
     if (const char *v = getenv("RTMI_LEAF_BIAS")) a.leaf_bias = atoi(v);
     // the first bounces (rays that still share the top of the tree in L2) are bound by instruction issue and gain from
-    // deferring the record tests; deeper bounces are bound by the gathers and lose, so they keep the voting kernel
-    int queue_low = 16;
-    uint32_t queue_depths = 2;
+    // deferring the record tests (bounce 2: 8 % since a node is three loads); on deeper bounces the two kernels are
+    // level, and those keep the voting kernel
+    int queue_low = 32; // swept 8 .. 64 after the node fetch shrank: 32 .. 64 level, 16 slower by 0.7 %
+    uint32_t queue_depths = 3;
     if (const char *v = getenv("RTMI_QUEUE_LOW")) queue_low = std::max(0, std::min(64, atoi(v)));
     if (const char *v = getenv("RTMI_QUEUE_DEPTHS")) queue_depths = (uint32_t)std::max(0, atoi(v));
     int tail_refill = 64; // lanes with a path below which a wave of the tail kernel takes new paths (64: as soon as one is idle)
