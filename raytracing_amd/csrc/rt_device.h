@@ -106,7 +106,7 @@ RT_DEV void keep_whole(F4 &v) {
 // pk_fma_probe.hip: runs of selects on vcc issue at a quarter of the rate of the same selects on a scalar register
 // pair); traversal code is full of such runs (near / far planes, sorting network, best-candidate update).  So the hot
 // code keeps its conditions as lane masks in scalar registers -- lanes(c), combined with & and | on the scalar unit --
-// and selects through them.  On the host a lane mask is a bool.
+// and selects through them.  On the host a lane mask is 0 or 1.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned long long LaneMask;
 RT_DEV LaneMask lanes(bool c) { return __builtin_amdgcn_ballot_w64(c); }
@@ -121,8 +121,8 @@ RT_DEV uint32_t select(LaneMask m, uint32_t a, uint32_t b) {
     return r;
 }
 #else
-typedef bool LaneMask;
-RT_DEV LaneMask lanes(bool c) { return c; }
+typedef unsigned LaneMask; // 0 or 1
+RT_DEV LaneMask lanes(bool c) { return c ? 1u : 0u; }
 RT_DEV float select(LaneMask m, float a, float b) { return m ? a : b; }
 RT_DEV uint32_t select(LaneMask m, uint32_t a, uint32_t b) { return m ? a : b; }
 #endif

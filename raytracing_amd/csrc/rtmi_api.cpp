@@ -838,7 +838,9 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     // the first bounces (rays that still share the top of the tree in L2) are bound by instruction issue and gain from
     // deferring the record tests (bounce 2: 8 % since a node is three loads); on deeper bounces the two kernels are
     // level, and those keep the voting kernel
-    int queue_low = 32; // swept 8 .. 64 after the node fetch shrank: 32 .. 64 level, 16 slower by 0.7 %
+    // swept 8 .. 64 on 5 M triangles after the node fetch shrank: 32 .. 64 level, 16 slower by 0.7 %; on a scene that
+    // fits L1 (a handful of nodes per ray, every path in the tail kernel) 32 is 7 % slower than 16
+    int queue_low = scene->info.node_bytes + scene->info.prim_bytes <= (32u << 10) ? 16 : 32;
     uint32_t queue_depths = 3;
     if (const char *v = getenv("RTMI_QUEUE_LOW")) queue_low = std::max(0, std::min(64, atoi(v)));
     if (const char *v = getenv("RTMI_QUEUE_DEPTHS")) queue_depths = (uint32_t)std::max(0, atoi(v));
@@ -883,8 +885,9 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
     // a bounce of the wavefront pair then mostly pays for is streaming ray, hit and queue planes through HBM, which the
     // tail kernel does not do (Cornell box 1920x1080 100 spp: 168.9 -> 149.3 ms with the tail kernel from bounce 1;
     // no difference on a 0.5 MB scene).
-    if (scene->info.node_bytes + scene->info.prim_bytes <= (32u << 10)) tail_rays = UINT64_MAX;
-    if (const char *v = getenv("RTMI_TAIL_RAYS")) tail_rays = (uint64_t)atoll(v);
+    bool tail_auto = true; // the threshold follows the size of the pass (below)
+    if (scene->info.node_bytes + scene->info.prim_bytes <= (32u << 10)) tail_rays = UINT64_MAX, tail_auto = false;
+    if (const char *v = getenv("RTMI_TAIL_RAYS")) tail_rays = (uint64_t)atoll(v), tail_auto = false;
     uint32_t deepest = 0, launches = 0;
     uint32_t n_done = 0; // pixels already precise enough for this call (use_done only)
     const uint32_t waves_per_block = rtk::BLOCK / 64;
@@ -929,6 +932,13 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
         paths += live;
         const uint64_t camera_rays = live;
         uint64_t expected = live; // rays expected to enter the bounce: the bound scaled by the last bounce's survival rate
+        // The tail kernel costs about 3 ms (its deepest path) + 0.31 ns per ray whatever it is given; the wavefront pair
+        // costs 0.23 .. 0.4 ns per ray, more the deeper the bounce and the fewer its rays.  On a full 1080p frame of 100
+        // samples the switch pays from about a sixth of the camera rays on (2^25 rays); a pass an eighth of that size (one
+        // rank's share of an 8-GPU job) would then hand everything after bounce 0 to the tail kernel, and does better
+        // keeping bounce 1 (swept 2^21 .. 2^25 on such a share: best at 6-8 M).
+        const uint64_t pass_tail_rays =
+            tail_auto ? std::min<uint64_t>(tail_rays, std::max<uint64_t>(6000000u, (uint64_t)(0.16 * (double)camera_rays))) : tail_rays;
         for (uint32_t depth = 0; depth < params->max_depth && live > 0; ++depth) {
             if (depth >= 2) {
                 const uint64_t before = live;
@@ -950,7 +960,7 @@ int rtmi_render(rtmi_scene *scene, rtmi_film *film, const rtmi_camera *camera, c
                 if (live == 0) break; // bounce depth - 1 already ran on an empty queue
                 expected = (uint64_t)((double)live * (double)live / (double)std::max<uint64_t>(before, 1));
             }
-            if (depth > 0 && expected < tail_rays) {
+            if (depth > 0 && expected < pass_tail_rays) {
                 // persistent waves: a resident grid at most, one lane per path when there are fewer paths than that
                 const uint64_t want = (live + rtk::BLOCK - 1) / rtk::BLOCK;
                 a.claim = 64u;
