@@ -81,7 +81,7 @@ struct SceneView {
 };
 
 // Node and record addresses are a uniform base plus a 32-bit byte offset (one shift; the hardware adds the base), which
-// is why a scene is limited to RT_MAX_ITEMS nodes and RT_MAX_ITEMS records.
+// is why a scene is limited to RT_MAX_ITEMS items (nodes + records + the padding of the placement).
 constexpr uint32_t RT_MAX_ITEMS = 1u << 26;
 RT_DEV const U4 *node_at(const SceneView &sv, uint32_t node) {
     return reinterpret_cast<const U4 *>(reinterpret_cast<const char *>(sv.nodes) + (node << 6));

@@ -818,9 +818,8 @@ extern "C" size_t hs_trace(void *p, const Ray *rays, size_t n, uint32_t *items, 
     return total;
 }
 
-// The item array of the tree (nodes and primitive records, 16 words each); returns the number of items.  In the default (breadth-first)
-// placement items [0, n_nodes) are the nodes breadth-first and the records follow
-// from the next even index on.
+// The item array of the tree (nodes and primitive records, 16 words each); returns the number of items.  Item 0 is
+// the root; the children of a node are neighbours (rt_device.h describes the node words).
 extern "C" size_t hs_items(void *p, uint32_t *out, size_t max_items) {
     Scene *s = (Scene *)p;
     const size_t n = s->bvh.n_items < max_items ? s->bvh.n_items : max_items;

@@ -58,6 +58,8 @@ def lib():
         L.hs_bounds.argtypes = [vp, fp, fp]
         L.hs_stack_high.restype = C.c_int
         L.hs_stack_high.argtypes = [vp]
+        L.hs_items.restype = C.c_size_t
+        L.hs_items.argtypes = [vp, vp, C.c_size_t]
         L.hs_geometry_triangles.restype = sz
         L.hs_geometry_triangles.argtypes = [vp, u32, vp, sz]
         L.hs_geometry_material.restype = u32
@@ -162,6 +164,13 @@ class HostSimScene:
 
     def stack_high(self):
         return int(self._l.hs_stack_high(self._h))
+
+    def items(self):
+        """The item array of the committed tree (nodes and primitive records), one row of 16 words per 64-byte item."""
+        n = int(self._l.hs_items(self._h, None, 0))
+        out = np.zeros((n, 16), dtype=np.uint32)
+        self._l.hs_items(self._h, out.ctypes.data, n)
+        return out
 
     def geometry_count(self):
         return int(self._l.hs_geometry_count(self._h))

@@ -281,6 +281,58 @@ def test_bvh_finds_every_primitive(oracle, hostsim):
     assert sh.stack_high() <= sh.info["stack_need"]
 
 
+@pytest.mark.parametrize("name,kw", [("cornell-box", {}), ("bunny", {}), ("dragon", {"levels": 1})])
+def test_node_items_name_their_children_by_one_index(hostsim, scene_classes, name, kw):
+    """The packed node the kernels read (48 of the item's 64 bytes, csrc/rt_device.h) against the plain child
+    references the builder keeps in the item's last four words: child k is item first + k, leaf bits and child count
+    agree, the children fill the first slots, a group never straddles more 128-byte lines than it must, the steps are
+    powers of two, every item is the child of exactly one node, and every record item holds a record."""
+    sh = hostsim.HostSimScene()
+    scene_classes[name].insert_into(sh, **kw)
+    sh.commit()
+    items = sh.items()
+    n_items = items.shape[0]
+    EMPTY, LEAF = 0xFFFFFFFF, 0x80000000
+    parents = np.zeros(n_items, dtype=np.int64)
+    is_node = np.zeros(n_items, dtype=bool)
+    todo, n_nodes, n_records = [0], 0, 0
+    is_node[0] = True
+    while todo:
+        it = todo.pop()
+        w = items[it]
+        n_nodes += 1
+        meta, first = int(w[10]), int(w[11])
+        leaf_bits, last = (meta >> 16) & 15, (meta >> 24) & 3
+        refs = [int(r) for r in w[12:16]]
+        present = [r != EMPTY for r in refs]
+        assert present == [k <= last for k in range(4)], "children fill slots 0 .. count - 1"
+        assert first % 2 == 0 and first + last < n_items, "a group starts on a line boundary"
+        for k in range(last + 1):
+            assert (refs[k] & 0x0FFFFFFF) == first + k
+            assert bool(refs[k] & LEAF) == bool(leaf_bits >> k & 1)
+            assert (refs[k] >> 28) & 7 == 0 or not refs[k] & LEAF, "one record per leaf"
+            parents[first + k] += 1
+            if refs[k] & LEAF:
+                n_records += 1
+            else:
+                is_node[first + k] = True
+                todo.append(first + k)
+        assert leaf_bits >> (last + 1) == 0
+        for half in (int(w[3]) & 0xFFFF, int(w[3]) >> 16, meta & 0xFFFF):
+            step = np.array([half << 16], dtype=np.uint32).view(np.float32)[0]
+            assert step > 0 and np.log2(float(step)) == round(np.log2(float(step))), "a step is a power of two"
+    assert n_nodes == sh.info["n_nodes"]
+    assert parents[0] == 0 and (parents[1:] <= 1).all()
+    used = parents > 0
+    used[0] = True
+    # every record item holds a record: its geometry word names an existing geometry
+    rec = items[used & ~is_node]
+    assert rec.shape[0] == n_records > 0
+    assert ((rec[:, 14] & 0x00FFFFFF) < sh.geometry_count()).all()
+    # what is neither node nor record is padding, and stays zero
+    assert not items[~used].any()
+
+
 def test_triangle_pairing_keeps_every_triangle_exact(oracle, hostsim):
     """Records hold two triangles that share an edge.  Whatever the pairing does with rotated, reversed, duplicate,
     non-manifold and degenerate triangles, every hit (distance, barycentrics, geometry and primitive id, normal) must
