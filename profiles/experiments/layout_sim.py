@@ -7,6 +7,10 @@ already fetched that line.  Layouts:
   current   nodes breadth-first in one array, records in leaf order in another (siblings share lines by accident of parity)
   pairs     one array of 128-byte pairs: a node with its largest child (node or record); leftover records two by two
 Usage: python profiles/experiments/layout_sim.py [levels] [pixel stride]
+
+The script reads the tree as it was laid out when the study was made (nodes breadth-first, then the records, four
+child references per node); the builder has since moved to neighbouring children named by one index, so it needs the
+sources of that time (the commit that added it) to run.
 """
 import ctypes as C
 import os
