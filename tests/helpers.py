@@ -115,3 +115,31 @@ def lab_camera(width, height, aperture=0.1):
     direction = look_at - look_from
     return types.Camera.new(width, height, np.float32(np.radians(55.0)), np.float32(1.4), look_from,
                             types.look_at_quat(direction, (0.0, 0.0, -1.0)), aperture)
+
+
+def insert_tiny_scene(scene, material, n_tri, n_sph):
+    """n_tri triangles in a row facing +z (neighbours share no edge: every triangle gets a record of its own) and n_sph
+    spheres behind them: scenes of one to a handful of primitives, whose trees have a root with one to four children."""
+    import numpy as np
+    if n_tri:
+        v, idx = [], []
+        for k in range(n_tri):
+            x = -1.0 + 0.7 * k
+            v += [(x, -0.3, -2.0 - 0.1 * k), (x + 0.5, -0.3, -2.0 - 0.1 * k), (x + 0.25, 0.4, -2.0 - 0.1 * k)]
+            idx.append((3 * k, 3 * k + 1, 3 * k + 2))
+        scene.insert_mesh(material, np.array(v, dtype=np.float32), np.array(idx, dtype=np.uint32))
+    for k in range(n_sph):
+        scene.insert_sphere(material, (-0.8 + 0.9 * k, 0.1, -3.5), 0.4)
+
+
+def tiny_scene_rays(dtype, n=4000, seed=3):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, dtype=dtype)
+    rays["org"] = rng.uniform(-0.2, 0.2, (n, 3)).astype(np.float32)
+    target = np.stack([rng.uniform(-1.5, 2.5, n), rng.uniform(-0.6, 0.7, n), np.full(n, -2.5)], 1).astype(np.float32)
+    d = target - rays["org"]
+    rays["dir"] = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]
+    rays["tnear"] = 1e-5
+    rays["tfar"] = np.inf
+    return rays

@@ -419,6 +419,32 @@ def test_triangle_pairing_keeps_every_triangle_exact(oracle, device):
     assert same_bits(film.download(), acc_o).all()
 
 
+@pytest.mark.parametrize("n_tri,n_sph", [(1, 0), (0, 1), (2, 0), (1, 1), (3, 0), (2, 2), (5, 1), (9, 3)])
+def test_tiny_scenes_match_brute_force(oracle, device, n_tri, n_sph):
+    """Trees whose root has one, two, three or four children (and the first two-level trees): the packed node names its
+    children by count and first item, so the small counts get a test of their own.  Hits equal brute force, bit for
+    bit, and a small render equals the oracle's."""
+    from raytracing_amd import api, types
+    from tests.helpers import insert_tiny_scene, tiny_scene_rays
+    so, sg = oracle.OracleScene(), api.HipScene(device)
+    for s in (so, sg):
+        m = s.insert_material(types.MaterialDescriptor("m", types.DiffuseBxDF((0.7, 0.6, 0.5))))
+        insert_tiny_scene(s, m, n_tri, n_sph)
+    so.commit()
+    world = sg.commit().into_world()
+    rays = tiny_scene_rays(oracle.RAY_DTYPE)
+    want = so.intersect(rays, oracle.ISECT_BRUTE)
+    assert world.intersect(rays).tobytes() == want.tobytes()
+    W, H = 64, 36
+    cam = types.Camera.from_dimensions(W, H)
+    xy = full_frame_xy(W, H)
+    acc_o, rays_o = so.render(cam, oracle.make_params(spp=4), xy)
+    film = api.Film(device, xy)
+    st = api.render(world, film, cam, 4)
+    assert st["rays"] == rays_o
+    assert same_bits(film.download(), acc_o).all()
+
+
 def test_deep_traversal_stack_spills(oracle, device):
     """60,000 large overlapping triangles: rays through the soup need more stack entries than the kernels keep in LDS
     (24 per lane), so the deeper entries go through the global spill buffer.  Hits must still equal brute force."""

@@ -333,6 +333,20 @@ def test_node_items_name_their_children_by_one_index(hostsim, scene_classes, nam
     assert not items[~used].any()
 
 
+@pytest.mark.parametrize("n_tri,n_sph", [(1, 0), (0, 1), (2, 0), (1, 1), (3, 0), (2, 2), (5, 1), (9, 3)])
+def test_tiny_scenes_on_host_match_brute_force(oracle, hostsim, n_tri, n_sph):
+    """Trees whose root has one, two, three or four children (and the first two-level trees): hits equal brute force."""
+    from tests.helpers import insert_tiny_scene, tiny_scene_rays
+    so, sh = oracle.OracleScene(), hostsim.HostSimScene()
+    for s in (so, sh):
+        insert_tiny_scene(s, 0, n_tri, n_sph)
+        s.commit()
+    rays = tiny_scene_rays(oracle.RAY_DTYPE)
+    want = so.intersect(rays, oracle.ISECT_BRUTE)
+    assert (want["geom_id"] != 0xFFFFFFFF).mean() > 0.05
+    assert sh.intersect(rays).tobytes() == want.tobytes()
+
+
 def test_triangle_pairing_keeps_every_triangle_exact(oracle, hostsim):
     """Records hold two triangles that share an edge.  Whatever the pairing does with rotated, reversed, duplicate,
     non-manifold and degenerate triangles, every hit (distance, barycentrics, geometry and primitive id, normal) must
