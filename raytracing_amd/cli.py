@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import struct
 import sys
 import time
 
@@ -64,13 +65,44 @@ class OutputBuffers:
                 self.channels[name][t.y_start:t.y_end, t.x_start:t.x_end] = block[:, :, 0]
 
 
-def write_pfm(path, img):
+def _exr_attribute(name, kind, value):
+    return name.encode() + b"\0" + kind.encode() + b"\0" + struct.pack("<i", len(value)) + value
+
+
+def write_exr(path, img):
+    """An OpenEXR file as the reference's `ImageBuffer<Rgb<f32>>::save("*.exr")` produces it for its readers
+    (crates/rt-cli/src/output/file_output.rs:28-37): one part, scan lines, the three channels B, G, R as 32-bit floats;
+    a one-channel image is replicated into the three (file_output.rs:24,35).  Written without compression, which every
+    reader accepts (the image crate picks a lossless compression; the pixels are the same)."""
     img = np.asarray(img, dtype=np.float32)
     if img.ndim == 2:
         img = np.repeat(img[:, :, None], 3, 2)
+    height, width = img.shape[:2]
+    channels = b"".join(c + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for c in (b"B", b"G", b"R")) + b"\0"
+    window = struct.pack("<4i", 0, 0, width - 1, height - 1)
+    header = struct.pack("<ii", 20000630, 2)
+    header += _exr_attribute("channels", "chlist", channels)
+    header += _exr_attribute("compression", "compression", b"\0")
+    header += _exr_attribute("dataWindow", "box2i", window)
+    header += _exr_attribute("displayWindow", "box2i", window)
+    header += _exr_attribute("lineOrder", "lineOrder", b"\0")
+    header += _exr_attribute("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    header += _exr_attribute("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0))
+    header += _exr_attribute("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    header += b"\0"
+    row_bytes = 12 * width
+    chunk = 8 + row_bytes
+    first = len(header) + 8 * height
+    offsets = (first + chunk * np.arange(height, dtype=np.uint64)).astype("<u8")
+    body = np.zeros((height, chunk), dtype=np.uint8)
+    body[:, 0:4] = np.arange(height, dtype="<i4").view(np.uint8).reshape(height, 4)
+    body[:, 4:8] = np.full(height, row_bytes, dtype="<i4").view(np.uint8).reshape(height, 4)
+    planes = np.ascontiguousarray(img[:, :, ::-1].transpose(0, 2, 1)).astype("<f4")  # per row: all B, all G, all R
+    body[:, 8:] = planes.view(np.uint8).reshape(height, row_bytes)
     with open(path, "wb") as fh:
-        fh.write(b"PF\n%d %d\n-1.0\n" % (img.shape[1], img.shape[0]))
-        fh.write(np.ascontiguousarray(img[::-1]).astype("<f4").tobytes())
+        fh.write(header)
+        fh.write(offsets.tobytes())
+        fh.write(body.tobytes())
 
 
 class FileOutput:
@@ -83,7 +115,7 @@ class FileOutput:
         os.makedirs(self.hdr_outdir, exist_ok=True)
         os.makedirs(self.ldr_outdir, exist_ok=True)
         for name, img in buffers.channels.items():
-            write_pfm(os.path.join(self.hdr_outdir, name + ".pfm"), img)
+            write_exr(os.path.join(self.hdr_outdir, name + ".exr"), img)
             np.save(os.path.join(self.hdr_outdir, name + ".npy"), img)
             ldr = np.nan_to_num(img, nan=0.0, posinf=1.0, neginf=0.0)
             ldr = np.round(np.clip(ldr, 0.0, 1.0) * 255.0).astype(np.uint8)

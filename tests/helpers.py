@@ -143,3 +143,51 @@ def tiny_scene_rays(dtype, n=4000, seed=3):
     rays["tnear"] = 1e-5
     rays["tfar"] = np.inf
     return rays
+
+
+def read_exr(path):
+    """Reader for the scan-line OpenEXR files of the CLI: checks the magic number, the version word and the attributes
+    every reader requires, then returns {channel name: (height, width) float32 array}.  Independent of the writer:
+    it follows the file's own header (channel list, data window, offset table)."""
+    import struct
+    import numpy as np
+    data = open(path, "rb").read()
+    magic, version = struct.unpack_from("<ii", data, 0)
+    assert magic == 20000630 and version & 0xFF == 2 and version >> 8 == 0, "single-part scan-line file, version 2"
+    pos, attrs = 8, {}
+    while data[pos] != 0:
+        end = data.index(b"\0", pos)
+        name = data[pos:end].decode()
+        pos = end + 1
+        end = data.index(b"\0", pos)
+        kind = data[pos:end].decode()
+        pos = end + 1
+        (size,) = struct.unpack_from("<i", data, pos)
+        attrs[name] = (kind, data[pos + 4:pos + 4 + size])
+        pos += 4 + size
+    pos += 1
+    for required in ("channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio",
+                     "screenWindowCenter", "screenWindowWidth"):
+        assert required in attrs, required
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    width, height = x1 - x0 + 1, y1 - y0 + 1
+    names, raw, p = [], attrs["channels"][1], 0
+    while raw[p] != 0:
+        end = raw.index(b"\0", p)
+        kind, linear, xs, ys = struct.unpack_from("<iB3xii", raw, end + 1)
+        assert kind == 2 and xs == 1 and ys == 1, "32-bit float channels, no subsampling"
+        names.append(raw[p:end].decode())
+        p = end + 1 + 16
+    assert names == sorted(names), "channels are stored in alphabetical order"
+    offsets = np.frombuffer(data, dtype="<u8", count=height, offset=pos)
+    out = {n: np.zeros((height, width), dtype=np.float32) for n in names}
+    for row in range(height):
+        o = int(offsets[row])
+        y, size = struct.unpack_from("<ii", data, o)
+        assert size == 4 * width * len(names)
+        line = np.frombuffer(data, dtype="<f4", count=width * len(names), offset=o + 8).reshape(len(names), width)
+        for k, n in enumerate(names):
+            out[n][y - y0] = line[k]
+    assert int(offsets[-1]) + 8 + 4 * width * len(names) == len(data), "nothing after the last scan line"
+    return out

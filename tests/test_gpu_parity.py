@@ -530,7 +530,7 @@ def test_allowed_error_adaptive_sampling(oracle, scene_classes, device):
 
 
 def test_cli_writes_the_reference_outputs(device, tmp_path):
-    """`rt-cli --scene debug --spp 4 -d 64x36 -o file`: seven channels, LDR JPEG + HDR files, RGB channels sRGB-encoded
+    """`rt-cli --scene debug --spp 4 -d 64x36 -o file`: seven channels, LDR JPEG + HDR EXR files, RGB channels sRGB-encoded
     (output/mod.rs:46-51), sky colour (186, 149, 254) as in the reference's renders."""
     from PIL import Image
     from raytracing_amd import cli
@@ -538,8 +538,11 @@ def test_cli_writes_the_reference_outputs(device, tmp_path):
                      "--seed", "3", "-r", "0..64x0..36"]) == 0
     names = ["Normal", "Position", "Albedo", "Color", "Variance", "Z", "RayDepth"]
     for n in names:
-        assert (tmp_path / "ldr" / (n + ".jpeg")).exists() and (tmp_path / "hdr" / (n + ".pfm")).exists()
+        assert (tmp_path / "ldr" / (n + ".jpeg")).exists() and (tmp_path / "hdr" / (n + ".exr")).exists()
     color = np.load(tmp_path / "hdr" / "Color.npy")
+    from tests.helpers import read_exr
+    exr = read_exr(tmp_path / "hdr" / "Color.exr")
+    assert all(same_bits(exr[c], color[:, :, k]).all() for k, c in enumerate("RGB"))
     assert color.shape == (36, 64, 3)
     corner = np.round(color[0, 0] * 255)
     assert tuple(corner) == (188.0, 149.0, 255.0) or np.allclose(corner, (188, 149, 255), atol=2)

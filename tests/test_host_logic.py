@@ -365,6 +365,27 @@ def test_triangle_pairing_keeps_every_triangle_exact(oracle, hostsim):
     assert got.tobytes() == want.tobytes()
 
 
+def test_exr_files_read_back(tmp_path):
+    """crates/rt-cli/src/output/file_output.rs:28-37 saves every channel as <name>.exr, RGB in 32-bit floats, luma
+    channels replicated into the three.  The CLI's writer against an independent reader of the format: every float
+    comes back bit for bit, NaN, infinities and denormals included."""
+    from raytracing_amd import cli
+    from tests.helpers import read_exr
+    rng = np.random.default_rng(4)
+    img = rng.normal(size=(37, 53, 3)).astype(np.float32)
+    img[0, 0] = (np.nan, np.inf, -np.inf)
+    img[1, 1] = (1e-42, -0.0, 3.4e38)
+    cli.write_exr(tmp_path / "Color.exr", img)
+    got = read_exr(tmp_path / "Color.exr")
+    assert sorted(got) == ["B", "G", "R"]
+    for k, n in enumerate("RGB"):
+        assert got[n].view(np.uint32).tobytes() == np.ascontiguousarray(img[:, :, k]).view(np.uint32).tobytes()
+    z = rng.uniform(0, 5, (9, 16)).astype(np.float32)
+    cli.write_exr(tmp_path / "Z.exr", z)
+    got = read_exr(tmp_path / "Z.exr")
+    assert all((got[n] == z).all() for n in "RGB")
+
+
 def test_host_types():
     from raytracing_amd import types
     r = types.RenderRange.parse("1..7x4..45")
