@@ -160,6 +160,10 @@ typedef struct rtmi_scene_info {
     uint32_t max_depth;  /* depth of the wide tree */
     float build_ms;      /* host time of commit (tree build + flatten + upload) */
     float sah_cost;
+    uint32_t n_records;      /* leaf records in the tree: one or two triangles or a sphere each; a record the builder cut
+                                at a plane (spatial split) is held once per part */
+    uint32_t spatial_splits; /* nodes of the binary build that cut records at a plane instead of sorting them into two
+                                sets (0 for a plain object-split tree; RTMI_SPATIAL=0 in the environment builds one) */
 } rtmi_scene_info;
 
 typedef struct rtmi_device rtmi_device;
@@ -209,8 +213,11 @@ int rtmi_scene_load_obj(rtmi_scene *scene, const char *path, const rtmi_transfor
                         uint32_t default_material, uint32_t *out_first_geom, uint32_t *out_n_geoms);
 
 /* EmbreeScene::commit / commit_with_progress (embree.rs:63-78): builds the SAH BVH on the host, flattens it to
- * 4-wide 64-byte GPU nodes over 64-byte primitive records and uploads them.  progress (may be NULL) is called with values
- * in [0,1]; returning 0 cancels (RTMI_ERR_CANCELLED). */
+ * 4-wide 64-byte GPU nodes over 64-byte primitive records and uploads them.  The reference asks Embree for
+ * RTCBuildQuality::HIGH (embree.rs:33-34), a build with spatial splits; this builder too cuts a record at a plane and
+ * keeps it once per part where its cost estimate says that pays (rtmi_scene_info.spatial_splits, n_records).  Hits do
+ * not depend on the tree.  progress (may be NULL) is called with values in [0,1]; returning 0 cancels
+ * (RTMI_ERR_CANCELLED). */
 typedef int (*rtmi_progress_fn)(double amount, void *user);
 int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user);
 

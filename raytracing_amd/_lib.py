@@ -62,7 +62,7 @@ class SceneInfo(C.Structure):
     _fields_ = [("n_prims", C.c_uint64), ("n_nodes", C.c_uint64), ("node_bytes", C.c_uint64),
                 ("prim_bytes", C.c_uint64), ("n_geoms", C.c_uint32), ("n_materials", C.c_uint32),
                 ("stack_need", C.c_uint32), ("max_depth", C.c_uint32), ("build_ms", C.c_float),
-                ("sah_cost", C.c_float)]
+                ("sah_cost", C.c_float), ("n_records", C.c_uint32), ("spatial_splits", C.c_uint32)]
 
 
 RAY_DTYPE = np.dtype([("org", np.float32, 3), ("tnear", np.float32), ("dir", np.float32, 3), ("tfar", np.float32)])

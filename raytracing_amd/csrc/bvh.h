@@ -26,18 +26,27 @@ struct Box {
 // per-child references it needed.)
 struct WideBvh {
     std::vector<rtd::F4> items;        // n_items x RT_NODE_F4: nodes in place (root = item 0), record slots zeroed
-    std::vector<uint32_t> prim_order;  // leaf slot -> index of the input primitive
+    std::vector<uint32_t> prim_order;  // leaf slot -> index of the input primitive (a primitive that spatial splits cut has several leaves)
     std::vector<uint32_t> record_item; // leaf slot -> item the primitive's record goes to
     uint32_t n_items = 0;              // nodes + record slots + padding
     uint32_t n_nodes = 0;
     uint32_t stack_need = 0; // worst-case traversal stack entries
     uint32_t depth = 0;
     float sah_cost = 0.0f;
+    uint32_t spatial_splits = 0; // inner nodes of the binary tree that cut references at a plane
 };
 
+// Padded bounds of the part of primitive `prim` that lies inside `region`; false when no part does.  Must be
+// conservative (contain every point of the primitive in the region, padded like the primitive's own box) and
+// monotonic (a smaller region gives a box inside the larger region's).
+typedef std::function<bool(uint32_t prim, const Box &region, Box &out)> ClipFn;
+
 // boxes: one padded box per primitive.  progress(amount in [0,1]) returning false cancels; build() then returns
-// false.  threads = worker threads for subtree builds (0 = hardware concurrency, capped at 16).
+// false.  threads = worker threads for subtree builds (0 = hardware concurrency, capped at 16).  With a clip function
+// the builder may cut primitives at planes (spatial splits, what Embree's RTC_BUILD_QUALITY_HIGH does for the
+// reference, crates/rt/src/aggregate/embree.rs:33-34); a cut primitive has one leaf per part, all naming the same
+// input primitive.  RTMI_SPATIAL=0 builds without.
 bool build(const std::vector<Box> &boxes, WideBvh &out, const std::function<bool(double)> &progress,
-           unsigned threads = 0);
+           unsigned threads = 0, const ClipFn &clip = ClipFn());
 
 } // namespace rtb

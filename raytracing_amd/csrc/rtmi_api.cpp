@@ -408,6 +408,8 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
     scene->info.stack_need = bvh.stack_need;
     scene->info.max_depth = bvh.depth;
     scene->info.sah_cost = bvh.sah_cost;
+    scene->info.n_records = (uint32_t)n_records;
+    scene->info.spatial_splits = bvh.spatial_splits;
     scene->info.build_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     scene->committed = true;

@@ -44,6 +44,48 @@ void pad_box(rtb::Box &b, float scene_scale) {
     }
 }
 
+// The part of triangle (a, b, c) inside `region` (Sutherland-Hodgman against the six planes, in double): its bounds are
+// merged into lo / hi; false when nothing of the triangle is inside.
+bool clip_triangle(const float *a, const float *b, const float *c, const rtb::Box &region, double lo[3], double hi[3]) {
+    double poly[2][12][3];
+    int n = 3, cur = 0;
+    for (int k = 0; k < 3; ++k) {
+        poly[0][0][k] = a[k];
+        poly[0][1][k] = b[k];
+        poly[0][2][k] = c[k];
+    }
+    for (int axis = 0; axis < 3 && n > 0; ++axis)
+        for (int side = 0; side < 2 && n > 0; ++side) {
+            const double plane = side == 0 ? (double)region.lo[axis] : (double)region.hi[axis];
+            const double sign = side == 0 ? 1.0 : -1.0;
+            double(*in)[3] = poly[cur], (*out)[3] = poly[cur ^ 1];
+            int m = 0;
+            for (int i = 0; i < n; ++i) {
+                const double *p = in[i], *q = in[(i + 1) % n];
+                const double dp = sign * (p[axis] - plane), dq = sign * (q[axis] - plane);
+                if (dp >= 0.0) {
+                    for (int k = 0; k < 3; ++k) out[m][k] = p[k];
+                    ++m;
+                }
+                if ((dp > 0.0 && dq < 0.0) || (dp < 0.0 && dq > 0.0)) {
+                    const double t = dp / (dp - dq);
+                    for (int k = 0; k < 3; ++k) out[m][k] = p[k] + t * (q[k] - p[k]);
+                    out[m][axis] = plane;
+                    ++m;
+                }
+            }
+            n = m;
+            cur ^= 1;
+        }
+    if (n == 0) return false;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fmin(lo[k], poly[cur][i][k]);
+            hi[k] = fmax(hi[k], poly[cur][i][k]);
+        }
+    return true;
+}
+
 } // namespace
 
 void apply_transform(const float translation[3], const float scale[3], const float rot[4], float p[3]) {
@@ -227,9 +269,39 @@ bool build_scene(const std::vector<HostPrim> &prims, rtb::WideBvh &bvh, size_t *
         if (prims[i].geom >= geom_first.size()) geom_first.resize(prims[i].geom + 1, NONE);
         if (geom_first[prims[i].geom] == NONE) geom_first[prims[i].geom] = (uint32_t)i;
     }
-    if (!rtb::build(rec_boxes, bvh, progress, 0)) return false;
-    if (n_records) *n_records = nr;
-    for (size_t slot = 0; slot < nr; ++slot) {
+    // What a spatial split of the builder asks for: the padded bounds of the part of record r inside a region.  A
+    // triangle is clipped exactly, a sphere by its box; the result is rounded outwards to f32 and padded like the
+    // primitive boxes, so a part keeps the margin the slab test relies on.
+    const rtb::ClipFn clip = [&](uint32_t r, const rtb::Box &region, rtb::Box &out) {
+        const uint32_t i = rec_first[r], j = mate[i];
+        double dlo[3] = {INFINITY, INFINITY, INFINITY}, dhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool any = false;
+        if (prims[i].is_sphere) {
+            rtb::Box sb;
+            prim_box(prims[i], sb);
+            any = true;
+            for (int k = 0; k < 3; ++k) {
+                dlo[k] = fmax((double)sb.lo[k], (double)region.lo[k]);
+                dhi[k] = fmin((double)sb.hi[k], (double)region.hi[k]);
+                if (!(dlo[k] <= dhi[k])) any = false;
+            }
+        } else {
+            any = clip_triangle(prims[i].a, prims[i].b, prims[i].c, region, dlo, dhi);
+            if (j != NONE) any = clip_triangle(prims[j].a, prims[j].b, prims[j].c, region, dlo, dhi) || any;
+        }
+        if (!any) return false;
+        for (int k = 0; k < 3; ++k) {
+            out.lo[k] = (float)dlo[k];
+            out.hi[k] = (float)dhi[k];
+            if ((double)out.lo[k] > dlo[k]) out.lo[k] = nextafterf(out.lo[k], -INFINITY);
+            if ((double)out.hi[k] < dhi[k]) out.hi[k] = nextafterf(out.hi[k], INFINITY);
+        }
+        pad_box(out, scene_scale);
+        return true;
+    };
+    if (!rtb::build(rec_boxes, bvh, progress, 0, clip)) return false;
+    if (n_records) *n_records = bvh.prim_order.size();
+    for (size_t slot = 0; slot < bvh.prim_order.size(); ++slot) {
         const uint32_t i = rec_first[bvh.prim_order[slot]], j = mate[i];
         const HostPrim &p = prims[i];
         float w[16];

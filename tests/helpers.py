@@ -191,3 +191,43 @@ def read_exr(path):
             out[n][y - y0] = line[k]
     assert int(offsets[-1]) + 8 + 4 * width * len(names) == len(data), "nothing after the last scan line"
     return out
+
+
+def mixed_scale_mesh(n_small=3000, n_long=12, seed=3):
+    """Small triangles scattered through a cube and a few long thin ones crossing it on a slant: the long ones' boxes
+    cover most of the scene, which is where a builder that cuts primitives at planes (spatial splits) differs from one
+    that only sorts them.  Returns (vertices float32 [V, 3], indices uint32 [T, 3])."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-5, 5, (n_small, 3))
+    a, b = rng.normal(size=(n_small, 3)) * 0.15, rng.normal(size=(n_small, 3)) * 0.15
+    v = [np.stack([c, c + a, c + b], 1).reshape(-1, 3)]
+    for _ in range(n_long):
+        p, q = rng.uniform(-5, 5, 3), rng.uniform(-5, 5, 3)
+        e = np.cross(q - p, rng.normal(size=3))
+        v.append(np.array([p, q, p + 0.8 * e / np.linalg.norm(e)]))
+    v = np.vstack(v).astype(np.float32)
+    return v, np.arange(v.shape[0], dtype=np.uint32).reshape(-1, 3)
+
+
+def needle_mesh(n=1500, seed=3, length=6.0, width=0.05):
+    """Long thin triangles of random orientation: nearly every box overlaps nearly every other."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-5, 5, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    e = rng.normal(size=(n, 3))
+    e -= (e * d).sum(1)[:, None] * d
+    e /= np.linalg.norm(e, axis=1)[:, None]
+    v = np.stack([c - d * length / 2, c + d * length / 2, c + e * width], 1).reshape(-1, 3).astype(np.float32)
+    return v, np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+
+
+def cube_rays(ray_dtype, n=6000, seed=1, half=8.0):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, dtype=ray_dtype)
+    rays["org"] = rng.uniform(-half, half, (n, 3))
+    d = rng.normal(size=(n, 3))
+    rays["dir"] = d / np.linalg.norm(d, axis=1)[:, None]
+    rays["tnear"] = 1e-5
+    rays["tfar"] = np.inf
+    return rays

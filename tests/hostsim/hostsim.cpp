@@ -161,6 +161,13 @@ int hs_commit(void *p, uint32_t out[4]) {
     return 0;
 }
 
+// Leaf records of the committed tree (a record cut by spatial splits counts once per part) and the number of splits.
+void hs_tree_stats(void *p, uint32_t out[2]) {
+    Scene *s = (Scene *)p;
+    out[0] = (uint32_t)s->bvh.prim_order.size();
+    out[1] = s->bvh.spatial_splits;
+}
+
 void hs_bounds(void *p, float lo[3], float hi[3]) {
     Scene *s = (Scene *)p;
     memcpy(lo, s->lo, 12);

@@ -56,6 +56,9 @@ def lib():
         L.hs_commit.restype = C.c_int
         L.hs_commit.argtypes = [vp, C.POINTER(u32)]
         L.hs_bounds.argtypes = [vp, fp, fp]
+        L.hs_tree_stats.argtypes = [vp, C.POINTER(u32)]
+        L.hs_trace.restype = C.c_size_t
+        L.hs_trace.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
         L.hs_stack_high.restype = C.c_int
         L.hs_stack_high.argtypes = [vp]
         L.hs_items.restype = C.c_size_t
@@ -154,7 +157,10 @@ class HostSimScene:
         out = (C.c_uint32 * 4)()
         if self._l.hs_commit(self._h, out):
             raise RuntimeError("hs_commit failed")
-        self.info = {"n_prims": out[0], "n_nodes": out[1], "stack_need": out[2], "max_depth": out[3]}
+        stats = (C.c_uint32 * 2)()
+        self._l.hs_tree_stats(self._h, stats)
+        self.info = {"n_prims": out[0], "n_nodes": out[1], "stack_need": out[2], "max_depth": out[3],
+                     "n_records": stats[0], "spatial_splits": stats[1]}
         return self
 
     def bounding_box(self):
@@ -171,6 +177,17 @@ class HostSimScene:
         out = np.zeros((n, 16), dtype=np.uint32)
         self._l.hs_items(self._h, out.ctypes.data, n)
         return out
+
+    def visits(self, rays):
+        """(inner-node visits, record tests) per ray of the closest-hit traversal of `rays`."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        n = rays.shape[0]
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        total = int(self._l.hs_trace(self._h, rays.ctypes.data, n, None, 0, offs.ctypes.data))
+        buf = np.zeros(max(total, 1), dtype=np.uint32)
+        self._l.hs_trace(self._h, rays.ctypes.data, n, buf.ctypes.data, total, offs.ctypes.data)
+        rec = int(((buf[:total] & 0x80000000) != 0).sum())
+        return (total - rec) / n, rec / n
 
     def geometry_count(self):
         return int(self._l.hs_geometry_count(self._h))

@@ -419,6 +419,46 @@ def test_triangle_pairing_keeps_every_triangle_exact(oracle, device):
     assert same_bits(film.download(), acc_o).all()
 
 
+@pytest.mark.parametrize("mesh,gain", [("mixed", None), ("mixed", "1.3"), ("needles", "1.3")])
+def test_spatial_splits_keep_every_hit(oracle, device, monkeypatch, mesh, gain):
+    """Trees whose builder cut records at planes (spatial splits; a cut record is held once per part, and a ray may
+    test it more than once): hits equal brute force bit for bit, a render equals the oracle's accumulators and ray
+    count.  Default settings cut the mixed-scale mesh because it pays; RTMI_SPATIAL_GAIN above 1 forces many more cuts."""
+    from raytracing_amd import api, types
+    from tests.helpers import cube_rays, mixed_scale_mesh, needle_mesh
+    if gain is not None:
+        monkeypatch.setenv("RTMI_SPATIAL_GAIN", gain)
+    v, t = mixed_scale_mesh() if mesh == "mixed" else needle_mesh()
+    so, sg = oracle.OracleScene(), api.HipScene(device)
+    for s in (so, sg):
+        m = s.insert_material(types.MaterialDescriptor("m", types.DiffuseBxDF((0.7, 0.6, 0.5))))
+        s.insert_mesh(m, v, t)
+        s.insert_sphere(m, (1.0, -2.0, 0.5), 1.5)
+    so.commit()
+    world = sg.commit().into_world()
+    info = world.info()
+    assert info["spatial_splits"] > (10 if gain is None else 100) and info["n_records"] > t.shape[0] + 1
+    rays = cube_rays(oracle.RAY_DTYPE)
+    want = so.intersect(rays, oracle.ISECT_BRUTE)
+    assert (want["geom_id"] != 0xFFFFFFFF).mean() > 0.05
+    assert world.intersect(rays).tobytes() == want.tobytes()
+    W, H = 64, 36
+    cam = types.Camera.from_dimensions(W, H)
+    xy = full_frame_xy(W, H)
+    acc_o, rays_o = so.render(cam, oracle.make_params(spp=4), xy)
+    film = api.Film(device, xy)
+    st = api.render(world, film, cam, 4)
+    assert st["rays"] == rays_o
+    assert same_bits(film.download(), acc_o).all()
+    monkeypatch.setenv("RTMI_SPATIAL", "0")
+    plain = api.HipScene(device)
+    m = plain.insert_material(types.MaterialDescriptor("m", types.DiffuseBxDF((0.7, 0.6, 0.5))))
+    plain.insert_mesh(m, v, t)
+    plain.insert_sphere(m, (1.0, -2.0, 0.5), 1.5)
+    info = plain.commit().into_world().info()
+    assert info["spatial_splits"] == 0 and info["n_records"] == t.shape[0] + 1
+
+
 @pytest.mark.parametrize("n_tri,n_sph", [(1, 0), (0, 1), (2, 0), (1, 1), (3, 0), (2, 2), (5, 1), (9, 3)])
 def test_tiny_scenes_match_brute_force(oracle, device, n_tri, n_sph):
     """Trees whose root has one, two, three or four children (and the first two-level trees): the packed node names its

@@ -51,7 +51,7 @@ def test_structure_layouts_match_the_header():
     assert _lib.RAY_DTYPE.itemsize == 32 and _lib.HIT_DTYPE.itemsize == 48
     assert C.sizeof(_lib.Camera) == 52 and C.sizeof(_lib.TransformPOD) == 40
     assert C.sizeof(_lib.RenderParams) == 40 and C.sizeof(_lib.RenderStats) == 48
-    assert C.sizeof(_lib.SceneInfo) == 56 and C.sizeof(_lib.BounceProfile) == 32
+    assert C.sizeof(_lib.SceneInfo) == 64 and C.sizeof(_lib.BounceProfile) == 32
 
 
 def test_no_gpu_fails_loudly():
@@ -281,15 +281,20 @@ def test_bvh_finds_every_primitive(oracle, hostsim):
     assert sh.stack_high() <= sh.info["stack_need"]
 
 
-@pytest.mark.parametrize("name,kw", [("cornell-box", {}), ("bunny", {}), ("dragon", {"levels": 1})])
+@pytest.mark.parametrize("name,kw", [("cornell-box", {}), ("bunny", {}), ("dragon", {"levels": 1}), ("mixed-scale mesh", {})])
 def test_node_items_name_their_children_by_one_index(hostsim, scene_classes, name, kw):
     """The packed node the kernels read (48 of the item's 64 bytes, csrc/rt_device.h) against the plain child
     references the builder keeps in the item's last four words: child k is item first + k, leaf bits and child count
     agree, the children fill the first slots, a group never straddles more 128-byte lines than it must, the steps are
     powers of two, every item is the child of exactly one node, and every record item holds a record."""
     sh = hostsim.HostSimScene()
-    scene_classes[name].insert_into(sh, **kw)
+    if name in scene_classes:
+        scene_classes[name].insert_into(sh, **kw)
+    else:  # a tree with spatial splits: cut records are held once per part
+        from tests.helpers import mixed_scale_mesh
+        sh.insert_mesh(0, *mixed_scale_mesh())
     sh.commit()
+    assert name in scene_classes or sh.info["spatial_splits"] > 10
     items = sh.items()
     n_items = items.shape[0]
     EMPTY, LEAF = 0xFFFFFFFF, 0x80000000
@@ -327,7 +332,7 @@ def test_node_items_name_their_children_by_one_index(hostsim, scene_classes, nam
     used[0] = True
     # every record item holds a record: its geometry word names an existing geometry
     rec = items[used & ~is_node]
-    assert rec.shape[0] == n_records > 0
+    assert rec.shape[0] == n_records == sh.info["n_records"] > 0
     assert ((rec[:, 14] & 0x00FFFFFF) < sh.geometry_count()).all()
     # what is neither node nor record is padding, and stays zero
     assert not items[~used].any()
@@ -363,6 +368,43 @@ def test_triangle_pairing_keeps_every_triangle_exact(oracle, hostsim):
     assert (want["geom_id"] != 0xFFFFFFFF).mean() > 0.5
     assert set(np.unique(want["geom_id"]).tolist()) >= {0, 3, 4}
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("mesh,gain", [("mixed", None), ("mixed", "1.3"), ("needles", "1.3")])
+def test_spatial_splits_keep_every_hit(oracle, hostsim, monkeypatch, mesh, gain):
+    """The builder may cut a record at a plane and keep it once per part (spatial splits, what the reference asks of
+    Embree with RTCBuildQuality::HIGH, crates/rt/src/aggregate/embree.rs:33-34).  A cut tree must give the brute-force
+    hits bit for bit, like the uncut one; on the mixed-scale mesh the cuts pay by the builder's own cost estimate
+    (default settings) and rays test a third fewer records; RTMI_SPATIAL_GAIN above 1 forces cuts that do not, so that
+    heavily cut trees are covered too."""
+    from tests.helpers import cube_rays, mixed_scale_mesh, needle_mesh
+    v, t = mixed_scale_mesh() if mesh == "mixed" else needle_mesh()
+    rays = cube_rays(oracle.RAY_DTYPE)
+    so = oracle.OracleScene()
+    so.insert_mesh(0, v, t)
+    so.insert_sphere(0, (1.0, -2.0, 0.5), 1.5)
+    so.commit()
+    want = so.intersect(rays, oracle.ISECT_BRUTE)
+    assert (want["geom_id"] != 0xFFFFFFFF).mean() > 0.05
+    stats = {}
+    for spatial in ("0", "1"):
+        monkeypatch.setenv("RTMI_SPATIAL", spatial)
+        if gain is not None:
+            monkeypatch.setenv("RTMI_SPATIAL_GAIN", gain)
+        sh = hostsim.HostSimScene()
+        sh.insert_mesh(0, v, t)
+        sh.insert_sphere(0, (1.0, -2.0, 0.5), 1.5)
+        sh.commit()
+        assert sh.intersect(rays).tobytes() == want.tobytes()
+        assert sh.stack_high() <= sh.info["stack_need"]
+        stats[spatial] = (sh.info, sh.visits(rays))
+    plain, cut = stats["0"], stats["1"]
+    assert plain[0]["spatial_splits"] == 0 and plain[0]["n_records"] == t.shape[0] + 1  # no two triangles share an edge
+    assert cut[0]["spatial_splits"] > (10 if gain is None else 100)
+    assert cut[0]["n_records"] > plain[0]["n_records"]
+    if mesh == "mixed":
+        assert cut[1][1] < 0.8 * plain[1][1], "fewer record tests per ray"
+        assert cut[1][0] < plain[1][0], "and fewer node visits"
 
 
 def test_exr_files_read_back(tmp_path):
