@@ -2,7 +2,7 @@
 code, tests/hostsim), on the Cornell box, the bunny and the dragon stand-in.  Rays: camera rays of a coarse grid of
 pixels, then two generations of bounce rays (uniform random directions from the hit points); for the two synthetic
 meshes of tests/helpers.py (small triangles with a few long slanted ones among them; a soup of needles) random rays
-through their cube instead of camera rays.  RTMI_SPATIAL_GAIN, RTMI_SPATIAL_ALPHA, RTMI_SPATIAL_LARGE in the
+through their cube instead of camera rays, and the same for a soup of 200 000 triangles of mixed sizes.  RTMI_SPATIAL_GAIN, RTMI_SPATIAL_ALPHA, RTMI_SPATIAL_LARGE in the
 environment move the builder's thresholds (csrc/bvh.cpp).
 Usage: python profiles/experiments/spatial_splits.py [dragon levels=5]"""
 import ctypes as C
@@ -67,6 +67,15 @@ def insert_needles(s):
     s.insert_mesh(0, *needle_mesh(20000))
 
 
+def insert_soup(s, n=200000):
+    """Triangles of sizes between 0.003 and 2 thrown into a cube of 20: large and small ones overlap everywhere."""
+    rng = np.random.default_rng(5)
+    c = rng.uniform(-10, 10, (n, 3))
+    size = 10.0 ** rng.uniform(-2.5, 0.3, (n, 1, 1))
+    v = (c[:, None, :] + rng.normal(size=(n, 3, 3)) * size).reshape(-1, 3).astype(np.float32)
+    s.insert_mesh(0, v, np.arange(3 * n, dtype=np.uint32).reshape(-1, 3))
+
+
 def cube(sh, rng, n=20000, half=8.0):
     r = np.zeros(n, dtype=HS.RAY_DTYPE)
     r["org"] = rng.uniform(-half, half, (n, 3))
@@ -77,7 +86,7 @@ def cube(sh, rng, n=20000, half=8.0):
     return r
 
 
-for name, insert in (("mixed-scale mesh", insert_mixed), ("20000 needles", insert_needles),
+for name, insert in (("mixed-scale mesh", insert_mixed), ("soup of 200000", insert_soup), ("20000 needles", insert_needles),
                      ("cornell", lambda s: scenes.CornellBoxScene.insert_into(s)),
                      ("bunny", lambda s: scenes.StandfordBunnyScene.insert_into(s)),
                      ("dragon stand-in", lambda s: scenes.DragonScene.insert_into(s, levels=levels))):
