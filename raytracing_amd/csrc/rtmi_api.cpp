@@ -358,6 +358,11 @@ int rtmi_scene_commit(rtmi_scene *scene, rtmi_progress_fn progress, void *user) 
     if (progress) cb = [progress, user](double a) { return progress(a, user) != 0; };
     if (!rts::build_scene(scene->prims, bvh, &n_records, scene->lo, scene->hi, cb))
         return fail(RTMI_ERR_CANCELLED, "commit cancelled by the progress callback");
+    // the quantised child boxes span at most 255 steps of 2^40; a non-finite coordinate lands here too (a NaN corner is
+    // left out of the bounds, and no ray hits its triangle anyway)
+    for (int k = 0; k < 3 && n > 0; ++k)
+        if (!(fabsf(scene->lo[k]) <= 1e14f) || !(fabsf(scene->hi[k]) <= 1e14f))
+            return fail(RTMI_ERR_LIMIT, "scene bounds beyond 1e14 units (or not finite): not representable in the tree's boxes");
     if (bvh.n_items >= rtd::RT_MAX_ITEMS)
         return fail(RTMI_ERR_LIMIT, "scene too large: more than 2^26 BVH nodes and primitive records");
     if (bvh.stack_need > rtk::MAX_STACK)

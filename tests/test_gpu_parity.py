@@ -333,6 +333,21 @@ def test_error_behaviour(device):
         sg.insert_sphere(0, (0, 0, 0), 1.0)  # immutable once committed
     with pytest.raises(api.RtmiError):
         sg.commit()
+    # coordinates the tree's boxes cannot hold: refused at commit, not culled wrongly
+    for bad in (np.inf, 3e14):
+        sg4 = api.HipScene(device)
+        v = np.array([[0, 0, 0], [1, 0, 0], [0, bad, 0]], np.float32)
+        sg4.insert_mesh(0, v, np.array([[0, 1, 2]], np.uint32))
+        with pytest.raises(api.RtmiError) as err:
+            sg4.commit()
+        assert err.value.code == -6  # RTMI_ERR_LIMIT
+    # a NaN corner makes its triangle unhittable and nothing else
+    sg5 = api.HipScene(device)
+    v = np.array([[0, 0, -3], [1, 0, -3], [0, 1, -3], [np.nan, 0, -2], [1, 0, -2], [0, 1, -2]], np.float32)
+    sg5.insert_mesh(0, v, np.array([[0, 1, 2], [3, 4, 5]], np.uint32))
+    w5 = sg5.commit().into_world()
+    hit = w5.intersection_full(((0.2, 0.2, 0.0), (0.0, 0.0, -1.0)))
+    assert hit is not None and hit["prim_id"] == 0 and hit["t"] == 3.0
     # a progress callback that cancels
     sg2 = api.HipScene(device)
     sg2.insert_sphere(0, (0, 0, 0), 1.0)
