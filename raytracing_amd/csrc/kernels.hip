@@ -268,14 +268,21 @@ struct QueueCursor {
     __device__ __forceinline__ bool finished() const { return c_next == c_end && drained && turn + 1u >= (uint32_t)SEGMENTS; }
 };
 
-// Hit record of the queue entry at plane offset `slot`: distance (+inf = miss), geometric normal, geometry word.
+// Hit record of the queue entry at plane offset `slot`: geometry word (RT_EMPTY = miss) and, for a hit, distance and
+// geometric normal (shade_kernel reads those two for hits only, so a miss leaves them as they are).
 __device__ __forceinline__ void store_hit(float *__restrict__ hits, size_t H, uint32_t slot, float t, V3 ng, uint32_t code) {
-    stp(hits + 0 * H, slot, t);
-    stp(hits + 1 * H, slot, ng.x);
-    stp(hits + 2 * H, slot, ng.y);
-    stp(hits + 3 * H, slot, ng.z);
     stp(hits + 4 * H, slot, __builtin_bit_cast(float, code));
+    if (code != RT_EMPTY) {
+        stp(hits + 0 * H, slot, t);
+        stp(hits + 1 * H, slot, ng.x);
+        stp(hits + 2 * H, slot, ng.y);
+        stp(hits + 3 * H, slot, ng.z);
+    }
 }
+
+// Origin of every camera ray: the centre of the lens (camera_ray in rt_device.h; camera.rs:62-85 moves only the point
+// the ray aims at over the aperture).
+__device__ __forceinline__ V3 camera_origin(const RenderArgs &a) { return mk(a.camera.lens[0], a.camera.lens[1], a.camera.lens[2]); }
 
 // Camera rays of every path of a pass, in the implicit queue order of bounce 0, into the bounce's payload planes.
 // Padding entries (pixels past n_pixels, pixels that take no more samples) get a zero direction, which no camera ray
@@ -290,9 +297,8 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(RenderArgs a) {
     const Entry e = queue_entry(a, 0u, seg, i, nullptr);
     V3 org = mk(0.0f, 0.0f, 0.0f), dir = mk(0.0f, 0.0f, 0.0f);
     if (e.valid) camera_ray(a.camera, a.strata, a.flags, a.seed, a.pixels[2 * e.pix], a.pixels[2 * e.pix + 1], e.sample, org, dir);
-    stp(Q + 1 * H, pos, org.x);
-    stp(Q + 2 * H, pos, org.y);
-    stp(Q + 3 * H, pos, org.z);
+    // every camera ray starts at the centre of the lens (camera_ray): the kernels of bounce 0 take the origin from the
+    // camera, and only the direction travels through memory
     stp(Q + 4 * H, pos, dir.x);
     stp(Q + 5 * H, pos, dir.y);
     stp(Q + 6 * H, pos, dir.z);
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(RenderArgs a, uint32_t de
             uint32_t i;
             if (cur.take(!has_ray, i)) {
                 const uint32_t pos = cur.seg * a.seg_cap + i;
-                org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+                org = primary ? camera_origin(a) : mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
                 dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
                 if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
                     slot_out = pos;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) v
             uint32_t i;
             if (cur.take(!has_ray, i)) {
                 const uint32_t pos = cur.seg * a.seg_cap + i;
-                const V3 org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+                const V3 org = primary ? camera_origin(a) : mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
                 const V3 dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
                 if (!primary || dir.x != 0.0f || dir.y != 0.0f || dir.z != 0.0f) {
                     lds.slot_out[tid] = pos;
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
         const Entry e = queue_entry(a, depth, seg, i, Q + (size_t)seg * a.seg_cap);
         pid = e.pid;
         if (e.valid) {
-            org = mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
+            org = depth == 0u ? camera_origin(a) : mk(ldp(Q + 1 * H, pos), ldp(Q + 2 * H, pos), ldp(Q + 3 * H, pos));
             dir = mk(ldp(Q + 4 * H, pos), ldp(Q + 5 * H, pos), ldp(Q + 6 * H, pos));
             beta = mk(1.0f, 1.0f, 1.0f);
             if (depth != 0u) {
@@ -650,6 +656,9 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(RenderArgs a, uint32_t dep
             }
             if (cont) {
                 alive = true;
+            } else if (depth == 0u && !h.hit) {
+                // a camera ray that leaves the scene: its path is the sky colour and a ray_depth of 0, which
+                // accumulate_kernel knows from z == 0 (stored above) without reading them
             } else {
                 stp(S + 0 * P, pid, vo.radiance.x);
                 stp(S + 1 * P, pid, vo.radiance.y);
@@ -848,7 +857,13 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *
         for (uint32_t s = 0; s < a.samples; ++s) {
             const size_t pid = block_base + (size_t)s * PIXEL_BLOCK;
             const float w = 1.0f;
-            const float col[3] = {S[0 * P + pid], S[1 * P + pid], S[2 * P + pid]};
+            // z == 0: the camera ray hit nothing (a hit has z = t > 0).  Its radiance is the sky's under a throughput
+            // of one (shade_vertex: beta * sky, integrators/mod.rs:19), its ray_depth 0, its first-hit outputs zeros;
+            // none of them was stored
+            const float z = S[12 * P + pid];
+            const bool sky = z == 0.0f;
+            const float col[3] = {sky ? 1.0f * 0.5f : S[0 * P + pid], sky ? 1.0f * 0.3f : S[1 * P + pid],
+                                  sky ? 1.0f * 1.0f : S[2 * P + pid]};
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 acc[ch] += col[ch];
@@ -856,15 +871,13 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(RenderArgs a, float *
                 acc[6 + ch] = acc[6 + ch] + w * col[ch];
             }
             acc[9] += w;
-            // first-hit outputs of a camera ray that hit nothing are zeros that were never stored (z == 0 marks
-            // them); the sums never hold -0, so leaving out the addition of +0 changes no bit
-            const float z = S[12 * P + pid];
-            if (z != 0.0f) {
+            // the sums never hold -0, so leaving out the addition of the +0 first-hit outputs of such a ray changes no bit
+            if (!sky) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) acc[10 + k] = acc[10 + k] + S[(size_t)(3 + k) * P + pid];
             }
             acc[19] += z;
-            acc[20] += S[13 * P + pid];
+            acc[20] += sky ? 0.0f : S[13 * P + pid];
             acc[21] += count_inc;
             // crates/rt-cli/src/executor.rs:244-249: the pixel is done for this batch once all channels are precise
             if (a.allowed_error > 0.0f && channel_precise(acc[21], acc[0], acc[3], a.allowed_error) &&
