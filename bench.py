@@ -209,7 +209,7 @@ def emit(line):
 
 def make_roofline(args, device, world_scene, film, camera, info, profile, steps, extend_ms, gpu_ms, launches, world, share):
     """Roofline of the dominant kernel: the closest-hit launch of every bounce (BVH traversal + primitive tests;
-    extend_queue_kernel on the first two bounces, extend_kernel on the others: one piece of work scheduled two ways).
+    extend_queue_kernel on the first three bounces, extend_kernel on the others: one piece of work scheduled two ways).
 
     Times are this run's: HIP events around every launch on the library's stream, per bounce.  Bytes come from two
     places.  (1) Counters: profiles/traffic.json holds, per launch of one frame of this workload, the fabric read
@@ -533,7 +533,7 @@ def main():
         ms_per_step = elapsed / steps * 1e3
         value = total_rays / elapsed / 1e6
         # roofline of the dominant kernel (the traversal launches, one per bounce: BVH traversal + primitive tests of
-        # every ray of the bounce; extend_queue_kernel on the first two bounces, extend_kernel on the rest, the same
+        # every ray of the bounce; extend_queue_kernel on the first three bounces, extend_kernel on the rest, the same
         # work scheduled in two ways), from this rank's own launches: HIP events around every launch give its time, a separate untimed render
         # with the visit counters on gives the node and record fetches
         roofline = None
